@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo eye-pairs/sec of the EASU+RCAS hot path at 1683x1869 -> 2244x2492 (BASELINE.json
+config C2), achieved fraction of the HBM roofline for the dominant kernel, and the CPU oracle timed
+beside it.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU; batches shard, no data-path collective)
+
+A "step" = one pass of the hot path (PostProcessor::Apply for both eyes of every pair) over one
+batch of `--pairs` synthetic stereo pairs that are already resident in HBM.  Weak scaling: every
+rank owns its own batch.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable by a float4 copy
+
+WORKLOADS = {
+    # name: (inW, inH, outW, outH, in/out dtype, radius)
+    "C2": (1683, 1869, 2244, 2492, torch.uint8, 2.0),
+    "C4": (2244, 2492, 2916, 3240, torch.uint8, 2.0),
+    "C5": (2370, 2370, 3160, 3160, torch.float16, 0.5),
+}
+
+
+def synth_batch(n_img, w, h, dtype, device, base_seed):
+    """Structured synthetic eye images generated ON the consuming GPU: sinusoid gradients,
+    hard 45/135-degree edges, +-4/255 noise, a constant block; alpha = 1."""
+    out = torch.empty((n_img, h, w, 4), dtype=dtype, device=device)
+    y = torch.arange(h, device=device, dtype=torch.float32)[:, None]
+    x = torch.arange(w, device=device, dtype=torch.float32)[None, :]
+    period = max(16, min(w, h) // 6)
+    for i in range(n_img):
+        g = torch.Generator(device=device)
+        g.manual_seed(base_seed + i)
+        ph = torch.rand(3, generator=g, device=device) * 6.28
+        img = torch.empty((h, w, 3), dtype=torch.float32, device=device)
+        for c in range(3):
+            img[..., c] = 0.5 + 0.35 * torch.sin(x * (0.011 + 0.004 * c) + ph[c]) * torch.cos(y * (0.008 + 0.003 * c) - ph[c])
+        d45 = ((x + y) % period) < (period / 2)
+        d135 = ((x - y) % (period * 1.5)) < (period * 0.5)
+        img[..., 0] = torch.where(d45, img[..., 0] * 0.35, img[..., 0])
+        img[..., 1] = torch.where(d135, 1.0 - img[..., 1] * 0.5, img[..., 1])
+        img[..., 2] = torch.where(d45 & d135, torch.full_like(img[..., 2], 0.95), img[..., 2])
+        img += (torch.randint(-4, 5, (h, w, 3), generator=g, device=device).float() / 255.0)
+        img[h // 3:h // 3 + h // 8, w // 3:w // 3 + w // 8, :] = torch.tensor([0.25, 0.5, 0.75], device=device)
+        img.clamp_(0.0, 1.0)
+        if dtype == torch.uint8:
+            out[i, ..., :3] = torch.floor(img * 255.0 + 0.5).to(torch.uint8)
+            out[i, ..., 3] = 255
+        else:
+            out[i, ..., :3] = img.to(dtype)
+            out[i, ..., 3] = 1.0
+    return out
+
+
+def time_events(fn, iters, stream):
+    """Average ms per call of fn() measured with HIP events recorded on `stream`."""
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(stream)
+    for _ in range(iters):
+        fn()
+    e.record(stream)
+    e.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def cpu_baseline(inW, inH, outW, outH, sharpness):
+    """The oracle (C restatement, OpenMP over all host cores) on ONE stereo pair of the same workload."""
+    from oracle import oracle as O
+    from tests import synth
+    cores = O.lib().ovo_max_threads()
+    imgs = [synth.structured_u8(inW, inH, synth.seed_for(0, e)) for e in range(2)]
+    O.fsr_pipeline_u8(imgs[0][:64, :64].copy(), 85, 85, sharpness=sharpness)  # warm the library
+    t0 = time.perf_counter()
+    for im in imgs:
+        O.fsr_pipeline_u8(im, outW, outH, sharpness=sharpness, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "eye-pairs/s", "cores": cores, "kind": "port",
+            "sample": "1 stereo pair %dx%d->%dx%d RGBA8, EASU+RCAS (UNORM8 intermediate), oracle/liboracle.so, %.2f s wall"
+                      % (inW, inH, outW, outH, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per GPU per step")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "strict"])
+    ap.add_argument("--fused", type=int, default=-1)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import openvr_fsr_amd as A
+    inW, inH, outW, outH, dtype, radius = WORKLOADS[args.workload]
+    sharpness = 0.9
+    prec = {"fp32": A.PRECISION_FP32, "fp16": A.PRECISION_FP16, "strict": A.PRECISION_FP32_STRICT}[args.precision]
+    n_img = 2 * args.pairs
+    base_seed = 0x5EED0000 + 2 * args.pairs * rank
+    texs = synth_batch(n_img, inW, inH, dtype, dev, base_seed)
+    outs = torch.empty((n_img, outH, outW, 4), dtype=dtype, device=dev)
+    pp = A.PostProcessor(fsr_enabled=1, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
+                         precision=prec, fused=args.fused, quantize_intermediate=1, device=local_rank)
+
+    def step():
+        pp.apply_batch(texs, outs, first_eye=A.EYE_LEFT, alternate_eyes=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    pairs_total = args.pairs * world * args.steps
+    value = pairs_total / dt
+    bpp = texs.element_size() * 4
+    algo_bytes_eye = bpp * (inW * inH + outW * outH)  # pipeline compulsory traffic per eye
+
+    # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream ---------
+    stream = torch.cuda.current_stream(dev)
+    roof = None
+    if rank == 0:
+        ms_step = time_events(step, max(5, args.steps // 2), stream)
+        # dominant kernel: EASU (two-pass) -- launch it alone over the same batch
+        pe = A.PostProcessor(fsr_enabled=1, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
+                             precision=prec, stage_mask=1, device=local_rank)
+        ms_easu = time_events(lambda: pe.apply_batch(texs, outs, first_eye=A.EYE_LEFT, alternate_eyes=True),
+                              max(5, args.steps // 2), stream)
+        pe.close()
+        easu_bytes = bpp * (inW * inH + outW * outH) * n_img
+        ach = easu_bytes / (ms_easu * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "easu_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                "launch_ms": round(ms_easu, 4), "algorithmic_bytes_per_launch": easu_bytes,
+                "pipeline_ms_per_step_events": round(ms_step, 4),
+                "pipeline_achieved_GBps": round(algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9, 1),
+                "note": "EASU is VALU-bound on this chip (see DESIGN.md); frac is reported against the HBM roof the contract names"}
+
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        cpu = cpu_baseline(inW, inH, outW, outH, sharpness)
+
+    if rank == 0:
+        line = {
+            "metric": "stereo eye-pairs/sec at 1683x1869->2244x2492 (EASU+RCAS)" if args.workload == "C2"
+                      else "stereo eye-pairs/sec (%s)" % args.workload,
+            "value": round(value, 2), "unit": "eye-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "strict": "f32"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, EASU+RCAS, sharpness 0.9, radius %.1f, UNORM8 intermediate"
+                                   % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F", radius),
+                       "pairs_per_gpu_per_step": args.pairs, "precision": args.precision,
+                       "parallelism": "batch sharded over %d GPU(s), no collective" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    pp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

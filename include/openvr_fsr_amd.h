@@ -1,0 +1,191 @@
+/*
+ * openvr_fsr_amd.h -- C ABI of the MI355X-native per-eye upscaler (FSR1 EASU + RCAS, NIS).
+ *
+ * This is the drop-in boundary for the reference's post-process hot path: everything
+ * vr::PostProcessor does between "game submitted an eye texture" and "upscaled texture handed to
+ * the compositor" (reference: src/postprocess/PostProcessor.{h,cpp}), with the D3D11 compute
+ * dispatches replaced by HIP kernels for gfx950.  Plain pointers and sizes only; no C++/torch
+ * types.  All image pointers are DEVICE pointers (the reference's input is an ID3D11Texture2D
+ * already resident on the GPU -- PostProcessor.cpp:133).  Nothing here throws; every entry point
+ * returns an ovrfsr_status and leaves outputs untouched on failure (PostProcessor.cpp:145-152).
+ *
+ * Reference interface each declaration replaces is cited as file:line under /root/reference/.
+ * The reference-side binding a maintainer would write is in INTEGRATION.md.
+ */
+#ifndef OPENVR_FSR_AMD_H
+#define OPENVR_FSR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define OVRFSR_API __attribute__((visibility("default")))
+#else
+#define OVRFSR_API
+#endif
+
+#define OVRFSR_ABI_VERSION 1u
+
+typedef enum ovrfsr_status {
+    OVRFSR_OK = 0,
+    OVRFSR_ERR_INVALID_ARGUMENT = 1, /* null / misaligned / inconsistent descriptor            */
+    OVRFSR_ERR_UNSUPPORTED = 2,      /* format or scale the path does not cover                 */
+    OVRFSR_ERR_HIP = 3,              /* a HIP runtime call failed; see ovrfsr_last_error()      */
+    OVRFSR_ERR_NO_DEVICE = 4,        /* no gfx950 device / kernels not loadable                 */
+    OVRFSR_ERR_DISABLED = 5,         /* ctx disabled itself after a failed (re)build, like
+                                        PostProcessor::enabled=false (PostProcessor.cpp:148-151)*/
+    OVRFSR_ERR_OUT_OF_MEMORY = 6
+} ovrfsr_status;
+
+/* vr::EVREye, headers/openvr.h:149-153 */
+typedef enum ovrfsr_eye { OVRFSR_EYE_LEFT = 0, OVRFSR_EYE_RIGHT = 1 } ovrfsr_eye;
+
+/* Pixel formats of the linear device buffers that stand in for ID3D11Texture2D.
+ * RGBA8_UNORM is what the reference allocates for its outputs (DetermineOutputFormat,
+ * PostProcessor.cpp:63-74); RGBA16F is the packed-half I/O of BASELINE config C5; RGBA32F exists
+ * so that parity can be measured on un-quantised results. */
+typedef enum ovrfsr_format {
+    OVRFSR_FORMAT_RGBA8_UNORM = 0,
+    OVRFSR_FORMAT_RGBA16F = 1,
+    OVRFSR_FORMAT_RGBA32F = 2
+} ovrfsr_format;
+
+/* Arithmetic the kernels run in.  The reference only ever compiles the fp32 bodies
+ * (`//#define A_HALF`, src/fsr/fsr_easu.hlsl:3).
+ *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp)
+ *   FP16         packed-half tap arithmetic (v_pk_*_f16), fp32 accumulation where it matters
+ *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
+ *                to the CPU oracle; a validation build, not a fast one */
+typedef enum ovrfsr_precision {
+    OVRFSR_PRECISION_FP32 = 0,
+    OVRFSR_PRECISION_FP16 = 1,
+    OVRFSR_PRECISION_FP32_STRICT = 2
+} ovrfsr_precision;
+
+/* Stands in for vr::Texture_t{handle,eType,eColorSpace} (headers/openvr.h:177-182) plus the
+ * D3D11_TEXTURE2D_DESC the reference queries from the handle (PostProcessor.cpp:137-139). */
+typedef struct ovrfsr_image {
+    void *data;           /* device pointer to texel (0,0); 16-byte aligned                      */
+    uint32_t width;       /* texels                                                              */
+    uint32_t height;      /* texels                                                              */
+    uint32_t pitch_bytes; /* distance between rows; multiple of the texel size; >= width*texel   */
+    uint32_t format;      /* ovrfsr_format                                                       */
+} ovrfsr_image;
+
+/* vr::VRTextureBounds_t, headers/openvr.h:609-613.  Only |uMax-uMin| > 0.5 is consulted
+ * ("texture contains only one eye", PostProcessor.cpp:146). */
+typedef struct ovrfsr_bounds { float uMin, vMin, uMax, vMax; } ovrfsr_bounds;
+
+/* The numeric fields of the reference's Config singleton that reach the GPU
+ * (src/postprocess/Config.h:10-17), plus the values the reference obtains from the OpenVR runtime
+ * (projection centres, PostProcessor.cpp:104-121) and implementation knobs of this library. */
+typedef struct ovrfsr_config {
+    uint32_t struct_size;    /* = sizeof(ovrfsr_config); ABI guard                               */
+    int32_t fsr_enabled;     /* Config::fsrEnabled: 0 -> apply() is a pass-through (output = input
+                                handle untouched, PostProcessor.cpp:135)                         */
+    int32_t use_nis;         /* Config::useNis                                                   */
+    int32_t debug_mode;      /* Config::debugMode: tints pixels outside the radius               */
+    float render_scale;      /* Config::renderScale; <1: out = in / scale, >=1: out = in * scale,
+                                both truncated to uint (PostProcessor.cpp:512-518)               */
+    float sharpness;         /* Config::sharpness, [0,1] (clamped where the reference clamps)    */
+    float radius;            /* Config::radius, in units of outH/2; 2.0 disables the mask        */
+    float proj_centre[4];    /* {Lx, Ly, Rx, Ry} in [0,1]: what CalculateProjectionCenter()
+                                returned for each eye; default 0.5                               */
+    uint32_t out_width;      /* explicit output size; 0,0 = derive from render_scale             */
+    uint32_t out_height;
+    int32_t precision;       /* ovrfsr_precision                                                 */
+    int32_t quantize_intermediate; /* 1 = EASU result is stored as UNORM8 before RCAS reads it,
+                                as the reference's R8G8B8A8_UNORM intermediate texture does
+                                (PostProcessor.cpp:348); 0 = intermediate kept in float          */
+    int32_t fused;           /* -1 auto, 0 two kernels through an HBM intermediate, 1 one kernel
+                                with the intermediate in LDS (same results for the same
+                                quantize_intermediate)                                           */
+    int32_t stage_mask;      /* 0 = the reference's stage selection (upscale iff scale != 1, sharpen
+                                iff !use_nis || scale == 1; PostProcessor.cpp:586-594).  1 = upscale
+                                stage only (BASELINE config C1 "EASU-only"), 2 = sharpen stage only  */
+    int32_t reserved[3];
+} ovrfsr_config;
+
+typedef struct ovrfsr_ctx ovrfsr_ctx; /* one per device; not thread-safe; distinct ctxs are independent */
+
+/* Config.h:10-17 defaults (fsrEnabled=false, renderScale=1, sharpness=0.75, radius=0.5), centres 0.5 */
+OVRFSR_API void ovrfsr_config_default(ovrfsr_config *cfg);
+
+/* Stands in for the implicit construction of the global `postProcessor` (VrHooks.cpp:19) +
+ * Config::Instance().  `device` is a HIP device ordinal. */
+OVRFSR_API int ovrfsr_create(int device, const ovrfsr_config *cfg, ovrfsr_ctx **out_ctx);
+OVRFSR_API void ovrfsr_destroy(ovrfsr_ctx *ctx);
+
+/* What the reference's hotkeys do: mutate Config then Reset() (PostProcessor.cpp:659-709). */
+OVRFSR_API int ovrfsr_set_config(ovrfsr_ctx *ctx, const ovrfsr_config *cfg);
+OVRFSR_API int ovrfsr_get_config(const ovrfsr_ctx *ctx, ovrfsr_config *cfg);
+
+/* PostProcessor::Reset() (PostProcessor.h:13, .cpp:166-194): drop cached constants and ctx-owned
+ * resources, re-enable after a failure. */
+OVRFSR_API int ovrfsr_reset(ovrfsr_ctx *ctx);
+
+/* Output size rule of PrepareResources (PostProcessor.cpp:512-518). */
+OVRFSR_API int ovrfsr_output_size(const ovrfsr_config *cfg, uint32_t in_width, uint32_t in_height,
+                                  uint32_t *out_width, uint32_t *out_height);
+
+/* PostProcessor::Apply(EVREye, const Texture_t*, const VRTextureBounds_t*, EVRSubmitFlags)
+ * (PostProcessor.h:12, .cpp:123-164).
+ *   in      the submitted eye texture (or the shared side-by-side texture).
+ *   bounds  may be NULL (= {0,0,1,1}, PostProcessor.cpp:128-131).
+ *   out     in/out.  If out->data is NULL the ctx-owned output image is used and *out is filled in
+ *           -- the reference's behaviour of swapping Texture_t::handle for its own texture
+ *           (PostProcessor.cpp:161), valid until the next apply on this ctx.  If out->data is set
+ *           the result is written there (width/height must equal the output size; format
+ *           selects the store conversion).  When the ctx is a pass-through (fsr disabled, or the
+ *           second Submit of a shared texture, PostProcessor.cpp:155-158) *out describes the
+ *           image the compositor should receive and nothing is launched.
+ *   stream  hipStream_t (NULL = default stream).  Launches are asynchronous on it.
+ * (Re)builds constants on first use and whenever the input size changes (PostProcessor.cpp:136-153). */
+OVRFSR_API int ovrfsr_apply(ovrfsr_ctx *ctx, int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds,
+                            ovrfsr_image *out, void *stream);
+
+/* Batch form for headless throughput: n eye images of identical shape, image i at
+ * base + i*stride_bytes, one launch over the whole batch.  Eye of image i is
+ * first_eye ^ (alternate_eyes ? (i & 1) : 0): a batch of stereo pairs is laid out L,R,L,R,...
+ * Each image is its own texture (textureContainsOnlyOneEye), outputs are caller-owned. */
+OVRFSR_API int ovrfsr_apply_batch(ovrfsr_ctx *ctx, uint32_t n, int first_eye, int alternate_eyes,
+                                  const ovrfsr_image *in0, size_t in_stride_bytes,
+                                  const ovrfsr_image *out0, size_t out_stride_bytes, void *stream);
+
+OVRFSR_API const char *ovrfsr_last_error(const ovrfsr_ctx *ctx);
+
+/* Averaged GPU time of the launches of the last apply, like the debug-mode timestamp queries
+ * (PostProcessor.cpp:579-628).  Blocks until that work is done.  Only recorded when
+ * cfg.debug_mode != 0. */
+OVRFSR_API int ovrfsr_last_gpu_time_ms(ovrfsr_ctx *ctx, float *ms);
+
+/* ---- constants-only entry points (known-answer tests; no GPU needed) ------------------------- */
+
+/* FsrEasuCon (src/fsr/ffx_fsr1.h:156-202); con = con0|con1|con2|con3 */
+OVRFSR_API void ovrfsr_easu_con(uint32_t con[16], float in_viewport_w, float in_viewport_h, float in_w,
+                                float in_h, float out_w, float out_h);
+/* FsrRcasCon (src/fsr/ffx_fsr1.h:662-672); `stops` = 2 - 2*clamp(sharpness,0,1) (PostProcessor.cpp:420-421) */
+OVRFSR_API void ovrfsr_rcas_con(uint32_t con[4], float stops);
+/* imageCentre / radius of UpscaleConstants and SharpenConstants (PostProcessor.cpp:298-305, 331-335) */
+OVRFSR_API void ovrfsr_mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t out_w, uint32_t out_h,
+                                      const float proj_centre[4], float cfg_radius,
+                                      int texture_contains_only_one_eye, int eye);
+/* NVScalerUpdateConfig / NVSharpenUpdateConfig (src/nis/NIS_Config.h:144-255) as PostProcessor.cpp:308,:433
+ * call them; cfg256 receives the 256-byte NISConfig; returns 1/0 like the reference's bool. */
+OVRFSR_API int ovrfsr_nis_scaler_config(void *cfg256, float sharpness, uint32_t in_w, uint32_t in_h,
+                                        uint32_t out_w, uint32_t out_h);
+OVRFSR_API int ovrfsr_nis_sharpen_config(void *cfg256, float sharpness, uint32_t in_w, uint32_t in_h);
+/* coef_scale / coef_usm, 64 phases x 8 taps (src/nis/NIS_Config.h:261-393) */
+OVRFSR_API const float *ovrfsr_nis_coef_scale(void);
+OVRFSR_API const float *ovrfsr_nis_coef_usm(void);
+
+OVRFSR_API uint32_t ovrfsr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENVR_FSR_AMD_H */

@@ -1,0 +1,78 @@
+// fsr_kernels.hip -- instantiates the gfx950 FSR1 kernels twice (product build and strict
+// validation build, see fsr_kernels.inc) and exposes typed launchers to the host launch manager.
+#include <hip/hip_runtime.h>
+#include "fsr_params.h"
+#include "fsr_launch.h"
+
+namespace ovrfsr_fast {
+#define OVRFSR_STRICT 0
+#pragma clang fp contract(fast)
+#include "fsr_kernels.inc"
+#undef OVRFSR_STRICT
+} // namespace ovrfsr_fast
+
+namespace ovrfsr_strict {
+#define OVRFSR_STRICT 1
+#pragma clang fp contract(off)
+#include "fsr_kernels.inc"
+#undef OVRFSR_STRICT
+} // namespace ovrfsr_strict
+#pragma clang fp contract(on)
+
+namespace ovrfsr {
+
+size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
+{
+    const bool wide = (prec == PREC_FP32_STRICT) || (in_fmt == FMT_RGBA32F);
+    const size_t ncell = (size_t)cellsW * cellsH;
+    const size_t col = (ncell * (wide ? 16 : 8) + 15) & ~(size_t)15;
+    return col + ncell * 16 + ncell * 4;
+}
+
+template <int I, int O>
+static hipError_t easu_go(bool strict, const EasuArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    if (strict) hipLaunchKernelGGL((ovrfsr_strict::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    return hipGetLastError();
+}
+template <int I, int O>
+static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t s)
+{
+    if (strict) hipLaunchKernelGGL((ovrfsr_strict::rcas_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((ovrfsr_fast::rcas_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+#define OVRFSR_DISPATCH_FMT(FN, ...)                                                                     \
+    switch (in_fmt * 3 + out_fmt) {                                                                      \
+    case 0: return FN<FMT_RGBA8, FMT_RGBA8>(__VA_ARGS__);                                                \
+    case 1: return FN<FMT_RGBA8, FMT_RGBA16F>(__VA_ARGS__);                                              \
+    case 2: return FN<FMT_RGBA8, FMT_RGBA32F>(__VA_ARGS__);                                              \
+    case 3: return FN<FMT_RGBA16F, FMT_RGBA8>(__VA_ARGS__);                                              \
+    case 4: return FN<FMT_RGBA16F, FMT_RGBA16F>(__VA_ARGS__);                                            \
+    case 5: return FN<FMT_RGBA16F, FMT_RGBA32F>(__VA_ARGS__);                                            \
+    case 6: return FN<FMT_RGBA32F, FMT_RGBA8>(__VA_ARGS__);                                              \
+    case 7: return FN<FMT_RGBA32F, FMT_RGBA16F>(__VA_ARGS__);                                            \
+    case 8: return FN<FMT_RGBA32F, FMT_RGBA32F>(__VA_ARGS__);                                            \
+    default: return hipErrorInvalidValue;                                                                \
+    }
+
+hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s)
+{
+    if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
+    const bool strict = prec == PREC_FP32_STRICT;
+    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    const size_t lds = easu_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH);
+    OVRFSR_DISPATCH_FMT(easu_go, strict, a, grid, lds, s)
+}
+
+hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uint32_t batch, hipStream_t s)
+{
+    if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
+    const bool strict = prec == PREC_FP32_STRICT;
+    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    OVRFSR_DISPATCH_FMT(rcas_go, strict, a, grid, s)
+}
+
+} // namespace ovrfsr

@@ -1,0 +1,11 @@
+// fsr_launch.h -- typed launchers implemented in fsr_kernels.hip, used by the host launch manager.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include "fsr_params.h"
+
+namespace ovrfsr {
+size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH);
+hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s);
+hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uint32_t batch, hipStream_t s);
+} // namespace ovrfsr

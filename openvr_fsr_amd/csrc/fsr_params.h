@@ -1,0 +1,64 @@
+// fsr_params.h -- kernel argument blocks shared by the host launch manager and the gfx950 kernels.
+// These play the role of the reference's constant buffers: UpscaleConstants
+// (src/postprocess/PostProcessor.cpp:276-283) and SharpenConstants (:403-407).
+#pragma once
+#include <stdint.h>
+
+namespace ovrfsr {
+
+enum : int { FMT_RGBA8 = 0, FMT_RGBA16F = 1, FMT_RGBA32F = 2 };
+enum : int { PREC_FP32 = 0, PREC_FP16 = 1, PREC_FP32_STRICT = 2 };
+
+// mask_mode: every 16x16 group inside the radius / every group outside / mixed (test per group)
+enum : uint32_t { MASK_ALL_INSIDE = 0, MASK_ALL_OUTSIDE = 1, MASK_MIXED = 2 };
+
+constexpr int kTileW = 32;  // output pixels per workgroup tile (two 16-px mask groups wide)
+constexpr int kTileH = 32;
+constexpr int kThreads = 256;
+
+struct BatchView {          // image i of a batch lives at base + i*stride
+    const uint8_t *in;
+    uint8_t *out;
+    uint64_t in_stride;     // bytes
+    uint64_t out_stride;    // bytes
+    uint32_t in_pitch;      // bytes per row
+    uint32_t out_pitch;
+    int32_t inW, inH, outW, outH;
+};
+
+struct MaskArgs {           // imageCentre / radius of the reference's cbuffers, one set per eye
+    uint32_t centre[2][4];  // [eye][c1x, c1y, c2x, c2y]
+    uint32_t r2;            // radius[1]
+    uint32_t mode[2];       // per eye: MASK_*
+    uint32_t first_eye;     // eye of image 0
+    uint32_t alternate;     // eye of image i = first_eye ^ (i & alternate)
+};
+
+struct EasuArgs {
+    BatchView v;
+    float sx, sy, cx, cy;   // FsrEasuCon con0 (the only row integer addressing needs)
+    MaskArgs m;
+    int32_t cellsW, cellsH; // LDS input tile extent (max over tiles) incl. the 1+2 apron
+    uint32_t tilesX, tilesY;
+};
+
+struct RcasArgs {
+    BatchView v;
+    float sharp;            // FsrRcasCon con[0] as float
+    uint32_t debug;         // const0[3]
+    MaskArgs m;
+    uint32_t tilesX, tilesY;
+};
+
+struct FusedArgs {
+    BatchView v;
+    float sx, sy, cx, cy;
+    float sharp;
+    uint32_t debug;
+    MaskArgs m;
+    int32_t cellsW, cellsH;
+    uint32_t tilesX, tilesY;
+    uint32_t quantize;      // 1: EASU result rounded to UNORM8 before RCAS (reference-faithful)
+};
+
+} // namespace ovrfsr

@@ -1,0 +1,340 @@
+// postprocessor.cpp -- see postprocessor.hpp.  Reference: src/postprocess/PostProcessor.cpp.
+#include "postprocessor.hpp"
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include "fsr_launch.h"
+
+namespace ovrfsr {
+
+static uint32_t texel_bytes(uint32_t fmt)
+{
+    return fmt == OVRFSR_FORMAT_RGBA8_UNORM ? 4u : fmt == OVRFSR_FORMAT_RGBA16F ? 8u : 16u;
+}
+
+// a*b+c with two roundings, identical to the kernels' mad_unfused (separate statements)
+static inline float mad2(float a, float b, float c)
+{
+    volatile float t = a * b;
+    return t + c;
+}
+
+PostProcessor::PostProcessor(int device, const ovrfsr_config &cfg) : device_(device), cfg_(cfg) {}
+
+PostProcessor::~PostProcessor()
+{
+    Reset();
+    if (evStart_) (void)hipEventDestroy(evStart_);
+    if (evEnd_) (void)hipEventDestroy(evEnd_);
+}
+
+int PostProcessor::Fail(int status, const std::string &what)
+{
+    lastError_ = what;
+    return status;
+}
+
+void PostProcessor::Reset()
+{
+    enabled_ = true;
+    initialized_ = false;
+    if (upscaled_) (void)hipFree(upscaled_);
+    if (sharpened_) (void)hipFree(sharpened_);
+    upscaled_ = sharpened_ = nullptr;
+    upscaledBytes_ = sharpenedBytes_ = 0;
+    lastSubmittedTexture_ = nullptr;
+    outputTexture_ = ovrfsr_image{};
+    eyeCount_ = 0;
+    timed_ = false;
+}
+
+int PostProcessor::SetConfig(const ovrfsr_config &cfg)
+{
+    // the reference's hotkeys mutate Config and then Reset() (PostProcessor.cpp:670-704)
+    cfg_ = cfg;
+    Reset();
+    return OVRFSR_OK;
+}
+
+int PostProcessor::CheckImage(const ovrfsr_image *img, const char *name)
+{
+    if (!img || !img->data) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": null image");
+    if (img->format > OVRFSR_FORMAT_RGBA32F) return Fail(OVRFSR_ERR_UNSUPPORTED, std::string(name) + ": unknown format");
+    const uint32_t tb = texel_bytes(img->format);
+    if (img->width == 0 || img->height == 0 || img->width > 16384 || img->height > 16384)
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": bad size");
+    if (img->pitch_bytes < img->width * tb || (img->pitch_bytes % tb) != 0)
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": bad pitch");
+    if ((reinterpret_cast<uintptr_t>(img->data) % tb) != 0)
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": data not texel-aligned");
+    return OVRFSR_OK;
+}
+
+int PostProcessor::EnsureBuffer(void **buf, size_t *have, size_t need)
+{
+    if (*have >= need) return OVRFSR_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    hipError_t e = hipMalloc(buf, need);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
+    *have = need;
+    return OVRFSR_OK;
+}
+
+uint32_t PostProcessor::IntermediateFormat() const
+{
+    // the reference's upscaledTexture is R8G8B8A8_UNORM (PostProcessor.cpp:348 via :63-74)
+    return cfg_.quantize_intermediate ? OVRFSR_FORMAT_RGBA8_UNORM : OVRFSR_FORMAT_RGBA32F;
+}
+
+void PostProcessor::PrepareUpscalingResources()
+{
+    easu_con(easuCon_, (float)inputWidth_, (float)inputHeight_, (float)inputWidth_, (float)inputHeight_,
+             (float)outputWidth_, (float)outputHeight_);
+    float sx, sy, cx, cy;
+    std::memcpy(&sx, &easuCon_[0], 4); std::memcpy(&sy, &easuCon_[1], 4);
+    std::memcpy(&cx, &easuCon_[2], 4); std::memcpy(&cy, &easuCon_[3], 4);
+    // LDS footprint of one 32x32 output tile: f-texel of first and last pixel, +1/+2 apron
+    auto extent = [](uint32_t outN, int tile, float s, float c) {
+        int best = 0;
+        for (uint32_t o0 = 0; o0 < outN; o0 += tile) {
+            uint32_t o1 = o0 + tile - 1 < outN ? o0 + tile - 1 : outN - 1;
+            int f0 = (int)std::floor(mad2((float)o0, s, c)), f1 = (int)std::floor(mad2((float)o1, s, c));
+            best = f1 - f0 + 4 > best ? f1 - f0 + 4 : best;
+        }
+        return best;
+    };
+    cellsW_ = extent(outputWidth_, kTileW, sx, cx);
+    cellsH_ = extent(outputHeight_, kTileH, sy, cy);
+}
+
+void PostProcessor::PrepareSharpeningResources()
+{
+    float s = cfg_.sharpness;
+    s = s < 1.0f ? s : 1.0f; // AClampF1(x,0,1) = max(0,min(x,1)), PostProcessor.cpp:420
+    s = s > 0.0f ? s : 0.0f;
+    rcas_con(rcasCon_, 2.f - 2 * s);
+    rcasCon_[3] = cfg_.debug_mode ? 1u : 0u; // :430
+}
+
+int PostProcessor::PrepareResources(const ovrfsr_image &in)
+{
+    inputWidth_ = in.width;
+    inputHeight_ = in.height;
+    inputFormat_ = in.format;
+    uint32_t ow = 0, oh = 0;
+    if (ovrfsr_output_size(&cfg_, in.width, in.height, &ow, &oh) != OVRFSR_OK || ow == 0 || oh == 0)
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "output size is zero");
+    outputWidth_ = ow;
+    outputHeight_ = oh;
+
+    const bool explicitSize = cfg_.out_width != 0 && cfg_.out_height != 0;
+    const bool scaleNotOne = explicitSize ? (ow != in.width || oh != in.height) : (cfg_.render_scale != 1.f);
+    doUpscale_ = cfg_.fsr_enabled && scaleNotOne;                       // :586
+    doSharpen_ = cfg_.fsr_enabled && (!cfg_.use_nis || !scaleNotOne);   // :591
+    if (cfg_.stage_mask == 1) doSharpen_ = false;                       // "EASU-only" (BASELINE C1)
+    if (cfg_.stage_mask == 2) doUpscale_ = false;
+    if (cfg_.stage_mask < 0 || cfg_.stage_mask > 2) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "bad stage_mask");
+    if (!doUpscale_ && (ow != in.width || oh != in.height))
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "sharpen-only needs output size == input size");
+    if (cfg_.use_nis) return Fail(OVRFSR_ERR_UNSUPPORTED, "NIS path not built yet");
+    if (cfg_.precision != OVRFSR_PRECISION_FP32 && cfg_.precision != OVRFSR_PRECISION_FP32_STRICT)
+        return Fail(OVRFSR_ERR_UNSUPPORTED, "precision not built yet");
+
+    for (int eye = 0; eye < 2; ++eye) {
+        mask_constants(centre_[eye], radius_, ow, oh, cfg_.proj_centre, cfg_.radius, textureContainsOnlyOneEye_ ? 1 : 0, eye);
+        maskMode_[eye] = classify_mask(centre_[eye], radius_[1], ow, oh);
+    }
+    if (doUpscale_) {
+        PrepareUpscalingResources();
+        const size_t lds = easu_lds_bytes(cfg_.precision, (int)in.format, cellsW_, cellsH_);
+        if (lds > 64 * 1024) return Fail(OVRFSR_ERR_UNSUPPORTED, "scale ratio needs more LDS than one tile may use");
+    }
+    if (doSharpen_) PrepareSharpeningResources();
+    if (cfg_.debug_mode && !evStart_) {
+        if (hipEventCreate(&evStart_) != hipSuccess || hipEventCreate(&evEnd_) != hipSuccess)
+            return Fail(OVRFSR_ERR_HIP, "hipEventCreate failed");
+    }
+    initialized_ = true;
+    return OVRFSR_OK;
+}
+
+void PostProcessor::FillMask(MaskArgs &m, int firstEye, int alternate) const
+{
+    std::memcpy(m.centre, centre_, sizeof(centre_));
+    m.r2 = radius_[1];
+    m.mode[0] = maskMode_[0];
+    m.mode[1] = maskMode_[1];
+    m.first_eye = (uint32_t)(firstEye & 1);
+    m.alternate = alternate ? 1u : 0u;
+}
+
+static BatchView make_view(const ovrfsr_image &in, size_t inStride, const ovrfsr_image &out, size_t outStride)
+{
+    BatchView v;
+    v.in = static_cast<const uint8_t *>(in.data);
+    v.out = static_cast<uint8_t *>(out.data);
+    v.in_stride = inStride;
+    v.out_stride = outStride;
+    v.in_pitch = in.pitch_bytes;
+    v.out_pitch = out.pitch_bytes;
+    v.inW = (int32_t)in.width; v.inH = (int32_t)in.height;
+    v.outW = (int32_t)out.width; v.outH = (int32_t)out.height;
+    return v;
+}
+
+int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                                  const ovrfsr_image &out, size_t outStride, hipStream_t stream)
+{
+    EasuArgs a;
+    a.v = make_view(in, inStride, out, outStride);
+    std::memcpy(&a.sx, &easuCon_[0], 4); std::memcpy(&a.sy, &easuCon_[1], 4);
+    std::memcpy(&a.cx, &easuCon_[2], 4); std::memcpy(&a.cy, &easuCon_[3], 4);
+    FillMask(a.m, firstEye, alternate);
+    a.cellsW = cellsW_; a.cellsH = cellsH_;
+    a.tilesX = (out.width + kTileW - 1) / kTileW;   // the reference dispatches 16x16 groups (:399);
+    a.tilesY = (out.height + kTileH - 1) / kTileH;  // a tile here is 2x2 of those
+    hipError_t e = launch_easu(cfg_.precision, (int)in.format, (int)out.format, a, n, stream);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("EASU launch: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
+}
+
+int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                                   const ovrfsr_image &out, size_t outStride, hipStream_t stream)
+{
+    RcasArgs a;
+    a.v = make_view(in, inStride, out, outStride);
+    std::memcpy(&a.sharp, &rcasCon_[0], 4);
+    a.debug = rcasCon_[3];
+    FillMask(a.m, firstEye, alternate);
+    a.tilesX = (out.width + kTileW - 1) / kTileW;
+    a.tilesY = (out.height + kTileH - 1) / kTileH;
+    hipError_t e = launch_rcas(cfg_.precision, (int)in.format, (int)out.format, a, n, stream);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("RCAS launch: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
+}
+
+// `in`/`out` describe image 0 of a batch of n; `out` is the FINAL destination.
+int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                                    const ovrfsr_image &out, size_t outStride, hipStream_t stream)
+{
+    if (cfg_.debug_mode && evStart_) (void)hipEventRecord(evStart_, stream);
+    int rc = OVRFSR_OK;
+    if (doUpscale_ && doSharpen_) {
+        ovrfsr_image mid;
+        mid.width = outputWidth_; mid.height = outputHeight_;
+        mid.format = IntermediateFormat();
+        mid.pitch_bytes = outputWidth_ * texel_bytes(mid.format);
+        const size_t midStride = (size_t)mid.pitch_bytes * outputHeight_;
+        rc = EnsureBuffer(&upscaled_, &upscaledBytes_, midStride * n);
+        if (rc != OVRFSR_OK) return rc;
+        mid.data = upscaled_;
+        rc = ApplyUpscaling(n, firstEye, alternate, in, inStride, mid, midStride, stream);
+        if (rc == OVRFSR_OK) rc = ApplySharpening(n, firstEye, alternate, mid, midStride, out, outStride, stream);
+    } else if (doUpscale_) {
+        rc = ApplyUpscaling(n, firstEye, alternate, in, inStride, out, outStride, stream);
+    } else if (doSharpen_) {
+        rc = ApplySharpening(n, firstEye, alternate, in, inStride, out, outStride, stream);
+    }
+    if (cfg_.debug_mode && evEnd_) { (void)hipEventRecord(evEnd_, stream); timed_ = true; }
+    return rc;
+}
+
+int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds, ovrfsr_image *out, hipStream_t stream)
+{
+    if (!enabled_) return Fail(OVRFSR_ERR_DISABLED, "post-processing disabled after an earlier failure; call reset");
+    if (!out) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "out is null");
+    int rc = CheckImage(in, "in");
+    if (rc != OVRFSR_OK) return rc;
+    if (eye != OVRFSR_EYE_LEFT && eye != OVRFSR_EYE_RIGHT) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "bad eye");
+    static const ovrfsr_bounds defaultBounds = {0, 0, 1, 1};
+    if (!bounds) bounds = &defaultBounds;
+
+    if (!cfg_.fsr_enabled) { // PostProcessor.cpp:135: texture is forwarded untouched
+        *out = *in;
+        return OVRFSR_OK;
+    }
+    hipError_t he = hipSetDevice(device_);
+    if (he != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
+
+    if (initialized_ && (in->width != inputWidth_ || in->height != inputHeight_ || in->format != inputFormat_))
+        Reset(); // "Texture size changed, recreating resources" (:139-142)
+    if (!initialized_) {
+        textureContainsOnlyOneEye_ = std::fabs(bounds->uMax - bounds->uMin) > .5f; // :146
+        rc = PrepareResources(*in);
+        if (rc != OVRFSR_OK) { enabled_ = false; return rc; } // :148-151
+    }
+
+    // caller-owned or ctx-owned final image
+    ovrfsr_image dst;
+    const bool stages = doUpscale_ || doSharpen_;
+    if (out->data) {
+        rc = CheckImage(out, "out");
+        if (rc != OVRFSR_OK) return rc;
+        if (out->width != outputWidth_ || out->height != outputHeight_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "out has the wrong size");
+        dst = *out;
+    } else {
+        dst.width = outputWidth_; dst.height = outputHeight_;
+        dst.format = in->format == OVRFSR_FORMAT_RGBA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM : in->format; // DetermineOutputFormat (:63-74)
+        dst.pitch_bytes = dst.width * texel_bytes(dst.format);
+        rc = EnsureBuffer(&sharpened_, &sharpenedBytes_, (size_t)dst.pitch_bytes * dst.height);
+        if (rc != OVRFSR_OK) return rc;
+        dst.data = sharpened_;
+    }
+
+    // a shared side-by-side texture is processed once, on the first Submit (:155-158)
+    if (eyeCount_ == 0 || textureContainsOnlyOneEye_ || in->data != lastSubmittedTexture_) {
+        if (stages) {
+            rc = ApplyPostProcess(1, textureContainsOnlyOneEye_ ? eye : OVRFSR_EYE_LEFT, 0, *in, 0, dst, 0, stream);
+            if (rc != OVRFSR_OK) return rc;
+            outputTexture_ = dst;
+        } else {
+            outputTexture_ = *in;
+        }
+    }
+    lastSubmittedTexture_ = in->data;
+    eyeCount_ = (eyeCount_ + 1) % 2;
+    *out = outputTexture_;
+    return OVRFSR_OK;
+}
+
+int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovrfsr_image *in0, size_t inStride,
+                              const ovrfsr_image *out0, size_t outStride, hipStream_t stream)
+{
+    if (!enabled_) return Fail(OVRFSR_ERR_DISABLED, "post-processing disabled after an earlier failure; call reset");
+    if (n == 0) return OVRFSR_OK;
+    if (n > 65535) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "batch too large for one launch (65535)");
+    int rc = CheckImage(in0, "in0");
+    if (rc != OVRFSR_OK) return rc;
+    rc = CheckImage(out0, "out0");
+    if (rc != OVRFSR_OK) return rc;
+    if (!cfg_.fsr_enabled) return Fail(OVRFSR_ERR_DISABLED, "fsr_enabled is 0: nothing to launch");
+    if (n > 1 && (inStride < (size_t)in0->pitch_bytes * in0->height || outStride < (size_t)out0->pitch_bytes * out0->height))
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "batch stride smaller than one image");
+    hipError_t he = hipSetDevice(device_);
+    if (he != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
+    if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || !textureContainsOnlyOneEye_))
+        Reset();
+    if (!initialized_) {
+        textureContainsOnlyOneEye_ = true;
+        rc = PrepareResources(*in0);
+        if (rc != OVRFSR_OK) { enabled_ = false; return rc; }
+    }
+    if (out0->width != outputWidth_ || out0->height != outputHeight_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "out has the wrong size");
+    if (!(doUpscale_ || doSharpen_)) return Fail(OVRFSR_ERR_UNSUPPORTED, "no stage selected (render_scale == 1 with NIS off would still sharpen)");
+    return ApplyPostProcess(n, firstEye, alternate, *in0, inStride, *out0, outStride, stream);
+}
+
+int PostProcessor::LastGpuTimeMs(float *ms)
+{
+    if (!ms) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "ms is null");
+    if (!timed_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "no timed apply (debug_mode off?)");
+    hipError_t e = hipEventSynchronize(evEnd_);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, evStart_, evEnd_);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("event timing: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
+}
+
+} // namespace ovrfsr

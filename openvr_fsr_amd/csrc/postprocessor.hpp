@@ -1,0 +1,89 @@
+// postprocessor.hpp -- HIP stream/launch manager that replaces the reference's D3D11 host pipeline
+// (src/postprocess/PostProcessor.{h,cpp}).  Same public shape -- Apply(eye, texture, bounds) and
+// Reset() -- same lazy (re)build rules, same stage selection; D3D11 resources become linear device
+// buffers and `context->Dispatch` becomes a kernel launch on a caller-provided HIP stream.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <string>
+#include "../../include/openvr_fsr_amd.h"
+#include "fsr_params.h"
+
+namespace ovrfsr {
+
+// host-side constant math (restates FsrEasuCon / FsrRcasCon / NVScalerUpdateConfig; see constants.cpp)
+void easu_con(uint32_t con[16], float inVpW, float inVpH, float inW, float inH, float outW, float outH);
+void rcas_con(uint32_t con[4], float stops);
+void mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t outW, uint32_t outH, const float proj[4],
+                    float cfgRadius, int onlyOneEye, int eye);
+uint32_t classify_mask(const uint32_t centre[4], uint32_t r2, uint32_t outW, uint32_t outH);
+
+class PostProcessor {
+public:
+    PostProcessor(int device, const ovrfsr_config &cfg);
+    ~PostProcessor();
+
+    // PostProcessor::Apply, PostProcessor.cpp:123-164
+    int Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds, ovrfsr_image *out, hipStream_t stream);
+    int ApplyBatch(uint32_t n, int firstEye, int alternate, const ovrfsr_image *in0, size_t inStride,
+                   const ovrfsr_image *out0, size_t outStride, hipStream_t stream);
+    // PostProcessor::Reset, PostProcessor.cpp:166-194
+    void Reset();
+    int SetConfig(const ovrfsr_config &cfg);
+    const ovrfsr_config &GetConfig() const { return cfg_; }
+    const char *LastError() const { return lastError_.c_str(); }
+    int LastGpuTimeMs(float *ms);
+
+private:
+    int device_;
+    ovrfsr_config cfg_;
+    std::string lastError_;
+
+    // PostProcessor.h:16-24
+    bool enabled_ = true;
+    bool initialized_ = false;
+    uint32_t inputWidth_ = 0, inputHeight_ = 0, outputWidth_ = 0, outputHeight_ = 0;
+    uint32_t inputFormat_ = 0;
+    bool textureContainsOnlyOneEye_ = true;
+    // PostProcessor.h:66-68
+    const void *lastSubmittedTexture_ = nullptr;
+    ovrfsr_image outputTexture_ = {};
+    int eyeCount_ = 0;
+
+    // stage selection, PostProcessor.cpp:530-535 / :586-594
+    bool doUpscale_ = false, doSharpen_ = false;
+
+    // "constant buffers", one per eye: PostProcessor.cpp:296-338, :419-460
+    uint32_t easuCon_[16] = {};
+    uint32_t rcasCon_[4] = {};
+    uint32_t centre_[2][4] = {};
+    uint32_t radius_[4] = {};
+    uint32_t maskMode_[2] = {};
+    int cellsW_ = 0, cellsH_ = 0;
+
+    // ctx-owned device buffers: upscaledTexture / sharpenedTexture, PostProcessor.h:43-45,58-59
+    void *upscaled_ = nullptr;
+    size_t upscaledBytes_ = 0;
+    void *sharpened_ = nullptr;
+    size_t sharpenedBytes_ = 0;
+
+    // debug-mode GPU timing, PostProcessor.h:72-82
+    hipEvent_t evStart_ = nullptr, evEnd_ = nullptr;
+    bool timed_ = false;
+
+    int Fail(int status, const std::string &what);
+    int CheckImage(const ovrfsr_image *img, const char *name);
+    int PrepareResources(const ovrfsr_image &in);                         // :498-561
+    void PrepareUpscalingResources();                                    // :285-383
+    void PrepareSharpeningResources();                                   // :409-481
+    int EnsureBuffer(void **buf, size_t *have, size_t need);
+    uint32_t IntermediateFormat() const;
+    int ApplyPostProcess(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                         const ovrfsr_image &out, size_t outStride, hipStream_t stream); // :563-638
+    int ApplyUpscaling(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                       const ovrfsr_image &out, size_t outStride, hipStream_t stream);   // :385-401
+    int ApplySharpening(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                        const ovrfsr_image &out, size_t outStride, hipStream_t stream);  // :483-496
+    void FillMask(MaskArgs &m, int firstEye, int alternate) const;
+};
+
+} // namespace ovrfsr
