@@ -4,7 +4,9 @@ Tolerances (stated, then asserted):
   * FP32_STRICT build: BIT-EXACT -- float outputs compare equal as uint32 words, UNORM8 outputs as bytes.
   * FP32 product build (FMA contraction, v_rcp_f32, colours accumulated in the 0..255 byte domain):
       float outputs  max-abs <= 2e-5   (north_star allows 1e-3)
-      UNORM8 outputs <= 1 LSB, and at most 0.1 % of channel values differ at all.
+      UNORM8 outputs of one pass <= 1 LSB, and at most 0.1 % of channel values differ at all;
+      UNORM8 outputs of EASU -> UNORM8 -> RCAS <= 5 LSB (a flipped rounding tie of the 8-bit intermediate
+      passes through RCAS's centre-tap gain of up to 4), same 0.1 % bound on how many differ.
 """
 import numpy as np
 import pytest
@@ -94,6 +96,7 @@ def test_masked_pipeline_strict_bit_exact(gpu, radius, proj, eye, debug):
 # ------------------------------------------------------------------------------------------------
 FLOAT_TOL = 2e-5
 LSB_FRACTION = 1e-3
+RCAS_LSB = 5
 
 
 @pytest.mark.parametrize("iw,ih,ow,oh,gen", SHAPES)
@@ -115,11 +118,12 @@ def test_pipeline_fp32_tolerance(gpu, iw, ih, ow, oh, gen):
     gotf = run_gpu(img8, ow, oh, np.float32, precision=FP32, sharpness=0.9, quantize_intermediate=0, fused=0)
     err = np.nanmax(np.abs(gotf - wantf))
     assert err <= 1e-4, err   # RCAS divides by local contrast: EASU's 2e-5 can grow a few x
-    # reference-faithful (8-bit intermediate): a 1-LSB flip of the intermediate is amplified by RCAS (<= 1+4*0.1875*... ~2 LSB)
+    # reference-faithful (8-bit intermediate): where a rounding tie of the intermediate flips by 1 LSB, RCAS
+    # amplifies it by up to 1/(1-4*0.1875) = 4 on the centre tap (+1 for the final rounding): <= 5 LSB, rarely.
     want8q = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9, quantize_intermediate=True)
     got8q = run_gpu(img8, ow, oh, np.uint8, precision=FP32, sharpness=0.9, quantize_intermediate=1, fused=0)
     mx, frac = lsb_stats(got8q, want8q)
-    assert mx <= 2 and frac <= 5e-3, (mx, frac)
+    assert mx <= RCAS_LSB and frac <= LSB_FRACTION, (mx, frac)
 
 
 def test_batch_matches_single(gpu):
@@ -139,4 +143,4 @@ def test_batch_matches_single(gpu):
         assert np.array_equal(got[i], single), i
         want = O.fsr_pipeline_u8(imgs[i], ow, oh, sharpness=0.9, radius=0.6, proj=proj, eye=i & 1)
         mx, frac = lsb_stats(got[i], want)
-        assert mx <= 2 and frac <= 5e-3, (i, mx, frac)
+        assert mx <= RCAS_LSB and frac <= LSB_FRACTION, (i, mx, frac)

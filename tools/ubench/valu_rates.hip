@@ -1,0 +1,188 @@
+// tools/ubench/valu_rates.hip -- issue-rate microbenchmark for the VALU / LDS instructions the FSR
+// kernels are made of (gfx950).  Prints cycles per wave-instruction per SIMD at full occupancy.
+//   hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates && ./valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <string>
+
+#define REP8(x) x x x x x x x x
+#define REP64(x) REP8(REP8(x))
+
+#define KERNEL(NAME, BODY, ...)                                                                   \
+    __global__ __launch_bounds__(256) void NAME(float *out, int iters, float seed)                 \
+    {                                                                                             \
+        float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
+        float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * .5f, b3 = a3 * .5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;        \
+        __shared__ float lds[4096];                                                               \
+        lds[threadIdx.x] = a0; lds[threadIdx.x + 256] = a1;                                        \
+        __syncthreads();                                                                          \
+        unsigned addr = (threadIdx.x * 16) & 8191;                                                \
+        (void)addr;                                                                               \
+        for (int i = 0; i < iters; ++i) { REP8(BODY) }                                             \
+        out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7; \
+    }
+
+// 8 independent instructions per BODY -> 64 per loop iteration
+#define V8(INS)                                                     \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a0) : "v"(b0));        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a1) : "v"(b1));        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a2) : "v"(b2));        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a3) : "v"(b3));        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a4) : "v"(b4));        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a5) : "v"(b5));        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a6) : "v"(b6));        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(a7) : "v"(b7));
+#define V8_2(INS)                                                   \
+    asm volatile(INS " %0, %0, %1" : "+v"(a0) : "v"(b0));            \
+    asm volatile(INS " %0, %0, %1" : "+v"(a1) : "v"(b1));            \
+    asm volatile(INS " %0, %0, %1" : "+v"(a2) : "v"(b2));            \
+    asm volatile(INS " %0, %0, %1" : "+v"(a3) : "v"(b3));            \
+    asm volatile(INS " %0, %0, %1" : "+v"(a4) : "v"(b4));            \
+    asm volatile(INS " %0, %0, %1" : "+v"(a5) : "v"(b5));            \
+    asm volatile(INS " %0, %0, %1" : "+v"(a6) : "v"(b6));            \
+    asm volatile(INS " %0, %0, %1" : "+v"(a7) : "v"(b7));
+#define V8_1(INS)                                                   \
+    asm volatile(INS " %0, %1" : "+v"(a0) : "v"(b0));                \
+    asm volatile(INS " %0, %1" : "+v"(a1) : "v"(b1));                \
+    asm volatile(INS " %0, %1" : "+v"(a2) : "v"(b2));                \
+    asm volatile(INS " %0, %1" : "+v"(a3) : "v"(b3));                \
+    asm volatile(INS " %0, %1" : "+v"(a4) : "v"(b4));                \
+    asm volatile(INS " %0, %1" : "+v"(a5) : "v"(b5));                \
+    asm volatile(INS " %0, %1" : "+v"(a6) : "v"(b6));                \
+    asm volatile(INS " %0, %1" : "+v"(a7) : "v"(b7));
+// packed f32: 64-bit register pairs
+#define P4(INS)                                                                                    \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p0) : "v"(q0));                                        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p1) : "v"(q1));                                        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p2) : "v"(q2));                                        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p3) : "v"(q3));                                        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p4) : "v"(q4));                                        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p5) : "v"(q5));                                        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p6) : "v"(q6));                                        \
+    asm volatile(INS " %0, %0, %1, %0" : "+v"(p7) : "v"(q7));
+#define P4_2(INS)                                                                                  \
+    asm volatile(INS " %0, %0, %1" : "+v"(p0) : "v"(q0));                                            \
+    asm volatile(INS " %0, %0, %1" : "+v"(p1) : "v"(q1));                                            \
+    asm volatile(INS " %0, %0, %1" : "+v"(p2) : "v"(q2));                                            \
+    asm volatile(INS " %0, %0, %1" : "+v"(p3) : "v"(q3));                                            \
+    asm volatile(INS " %0, %0, %1" : "+v"(p4) : "v"(q4));                                            \
+    asm volatile(INS " %0, %0, %1" : "+v"(p5) : "v"(q5));                                            \
+    asm volatile(INS " %0, %0, %1" : "+v"(p6) : "v"(q6));                                            \
+    asm volatile(INS " %0, %0, %1" : "+v"(p7) : "v"(q7));
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+#define PKERNEL(NAME, BODY)                                                                        \
+    __global__ __launch_bounds__(256) void NAME(float *out, int iters, float seed)                 \
+    {                                                                                             \
+        float s = seed + threadIdx.x;                                                             \
+        float2v p0 = {s, s + 1}, p1 = {s + 2, s + 3}, p2 = {s + 4, s + 5}, p3 = {s + 6, s + 7}, p4 = {s + 8, s + 9}, p5 = {s + 10, s + 11}, p6 = {s + 12, s + 13}, p7 = {s + 14, s + 15}; \
+        float2v q0 = p0 * .5f, q1 = p1 * .5f, q2 = p2 * .5f, q3 = p3 * .5f, q4 = p4 * .5f, q5 = p5 * .5f, q6 = p6 * .5f, q7 = p7 * .5f; \
+        for (int i = 0; i < iters; ++i) { REP8(BODY) }                                             \
+        float2v r = p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7 + q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;  \
+        out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y;                                           \
+    }
+
+KERNEL(k_fma_f32, V8("v_fma_f32"))
+KERNEL(k_mul_f32, V8_2("v_mul_f32"))
+KERNEL(k_add_f32, V8_2("v_add_f32"))
+KERNEL(k_min_f32, V8_2("v_min_f32"))
+KERNEL(k_min3_f32, V8("v_min3_f32"))
+KERNEL(k_med3_f32, V8("v_med3_f32"))
+KERNEL(k_pk_fma_f16, V8("v_pk_fma_f16"))
+KERNEL(k_pk_mul_f16, V8_2("v_pk_mul_f16"))
+KERNEL(k_pk_min_f16, V8_2("v_pk_min_f16"))
+KERNEL(k_fma_mix_f32, V8("v_fma_mix_f32"))
+KERNEL(k_fma_mixlo_f16, V8("v_fma_mixlo_f16"))
+KERNEL(k_cvt_f32_f16, V8_1("v_cvt_f32_f16"))
+KERNEL(k_cvt_f16_f32, V8_1("v_cvt_f16_f32"))
+KERNEL(k_cvt_f32_ubyte0, V8_1("v_cvt_f32_ubyte0"))
+KERNEL(k_rcp_f32, V8_1("v_rcp_f32"))
+KERNEL(k_rcp_f16, V8_1("v_rcp_f16"))
+KERNEL(k_sub_u32, V8_2("v_sub_u32"))
+KERNEL(k_lshrrev, V8_2("v_lshrrev_b32"))
+KERNEL(k_cvt_pkrtz, V8_2("v_cvt_pkrtz_f16_f32"))
+KERNEL(k_pk_add_f16, V8_2("v_pk_add_f16"))
+KERNEL(k_dot2_f32_f16, V8("v_dot2_f32_f16"))
+PKERNEL(k_pk_fma_f32, P4("v_pk_fma_f32"))
+PKERNEL(k_pk_mul_f32, P4_2("v_pk_mul_f32"))
+PKERNEL(k_pk_add_f32, P4_2("v_pk_add_f32"))
+
+// LDS reads: 8 independent reads then one wait
+#define L8(INS, W)                                                                                 \
+    asm volatile(INS " %0, %1" : "=v"(r0) : "v"(addr));                                              \
+    asm volatile(INS " %0, %1 offset:256" : "=v"(r1) : "v"(addr));                                   \
+    asm volatile(INS " %0, %1 offset:512" : "=v"(r2) : "v"(addr));                                   \
+    asm volatile(INS " %0, %1 offset:768" : "=v"(r3) : "v"(addr));                                   \
+    asm volatile(INS " %0, %1 offset:1024" : "=v"(r4) : "v"(addr));                                  \
+    asm volatile(INS " %0, %1 offset:1280" : "=v"(r5) : "v"(addr));                                  \
+    asm volatile(INS " %0, %1 offset:1536" : "=v"(r6) : "v"(addr));                                  \
+    asm volatile(INS " %0, %1 offset:1792" : "=v"(r7) : "v"(addr));                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define LKERNEL(NAME, TYPE, INS, STRIDE)                                                           \
+    __global__ __launch_bounds__(256) void NAME(float *out, int iters, float seed)                 \
+    {                                                                                             \
+        __shared__ __attribute__((aligned(16))) float lds[8192];                                   \
+        for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = seed + i;                           \
+        __syncthreads();                                                                          \
+        unsigned addr = (threadIdx.x & 63) * STRIDE + (threadIdx.x >> 6) * 4096;                    \
+        TYPE r0, r1, r2, r3, r4, r5, r6, r7;                                                       \
+        float acc = 0;                                                                            \
+        for (int i = 0; i < iters; ++i) { REP8(L8(INS, 0)) acc += ((float *)&r0)[0] + ((float *)&r7)[0]; } \
+        out[blockIdx.x * 256 + threadIdx.x] = acc + ((float *)&r1)[0] + ((float *)&r2)[0] + ((float *)&r3)[0] + ((float *)&r4)[0] + ((float *)&r5)[0] + ((float *)&r6)[0]; \
+    }
+typedef float float4v __attribute__((ext_vector_type(4)));
+LKERNEL(k_ds_read_b32, float, "ds_read_b32", 4)
+LKERNEL(k_ds_read_b64, float2v, "ds_read_b64", 8)
+LKERNEL(k_ds_read_b128, float4v, "ds_read_b128", 16)
+LKERNEL(k_ds_read_b64_s6, float2v, "ds_read_b64", 6 * 8 / 8 * 8)   // stride 0.75-ish pattern approximated below
+
+typedef void (*kern_t)(float *, int, float);
+
+static double run(kern_t k, float *d, int iters, int blocks)
+{
+    hipEvent_t s, e;
+    hipEventCreate(&s); hipEventCreate(&e);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, 8, 1.0f);
+    hipDeviceSynchronize();
+    hipEventRecord(s);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f);
+    hipEventRecord(e);
+    hipEventSynchronize(e);
+    float ms;
+    hipEventElapsedTime(&ms, s, e);
+    return ms;
+}
+
+int main()
+{
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    const double ghz = p.clockRate * 1e-6;
+    printf("device %s, %d CUs, %.2f GHz\n", p.gcnArchName, cus, ghz);
+    const int blocks = cus * 8; // 8 blocks x 4 waves = 32 waves/CU = 8 waves/SIMD
+    float *d;
+    hipMalloc(&d, sizeof(float) * 256 * blocks);
+    struct { const char *n; kern_t k; int per_iter; } ks[] = {
+        {"v_fma_f32", k_fma_f32, 64}, {"v_mul_f32", k_mul_f32, 64}, {"v_add_f32", k_add_f32, 64}, {"v_min_f32", k_min_f32, 64},
+        {"v_min3_f32", k_min3_f32, 64}, {"v_med3_f32", k_med3_f32, 64},
+        {"v_pk_fma_f32", k_pk_fma_f32, 64}, {"v_pk_mul_f32", k_pk_mul_f32, 64}, {"v_pk_add_f32", k_pk_add_f32, 64},
+        {"v_pk_fma_f16", k_pk_fma_f16, 64}, {"v_pk_mul_f16", k_pk_mul_f16, 64}, {"v_pk_add_f16", k_pk_add_f16, 64}, {"v_pk_min_f16", k_pk_min_f16, 64},
+        {"v_fma_mix_f32", k_fma_mix_f32, 64}, {"v_fma_mixlo_f16", k_fma_mixlo_f16, 64}, {"v_dot2_f32_f16", k_dot2_f32_f16, 64},
+        {"v_cvt_f32_f16", k_cvt_f32_f16, 64}, {"v_cvt_f16_f32", k_cvt_f16_f32, 64}, {"v_cvt_pkrtz_f16_f32", k_cvt_pkrtz, 64},
+        {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte0, 64},
+        {"v_rcp_f32", k_rcp_f32, 64}, {"v_rcp_f16", k_rcp_f16, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_lshrrev_b32", k_lshrrev, 64},
+        {"ds_read_b32", k_ds_read_b32, 64}, {"ds_read_b64", k_ds_read_b64, 64}, {"ds_read_b128", k_ds_read_b128, 64},
+    };
+    const int iters = 4000;
+    for (auto &k : ks) {
+        double ms = run(k.k, d, iters, blocks);
+        // per SIMD: 8 waves each issuing iters*per_iter instructions
+        double instr_per_simd = 8.0 * iters * k.per_iter;
+        double cyc = ms * 1e-3 * ghz * 1e9 / instr_per_simd;
+        printf("%-22s %8.3f ms  %6.2f cycles / wave-instruction / SIMD (at %.2f GHz nominal)\n", k.n, ms, cyc, ghz);
+    }
+    hipFree(d);
+    return 0;
+}
