@@ -1,0 +1,78 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares; host-side entry points behave
+like the reference's host code.  No GPU needed (no compute call is made)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import openvr_fsr_amd as A
+from openvr_fsr_amd import _capi as K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "openvr_fsr_amd.h")).read()
+    return sorted(set(re.findall(r"OVRFSR_API\s+[\w\s\*]+?\b(ovrfsr_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(A.library_path())
+    names = declared_symbols()
+    assert len(names) >= 18, names
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+
+
+def test_abi_version_and_struct_sizes():
+    L = A.library()
+    assert L.ovrfsr_abi_version() == 1
+    cfg = A.Config.default()
+    assert cfg.struct_size == C.sizeof(A.Config) == 80
+    assert C.sizeof(A.Image) == 24 and C.sizeof(A.Bounds) == 16
+
+
+def test_config_defaults_match_reference_config_h():
+    cfg = A.Config.default()   # src/postprocess/Config.h:10-17
+    assert cfg.fsr_enabled == 0 and cfg.use_nis == 0 and cfg.debug_mode == 0
+    assert cfg.render_scale == 1.0 and cfg.sharpness == 0.75 and cfg.radius == 0.5
+    assert list(cfg.proj_centre) == [0.5] * 4 and cfg.quantize_intermediate == 1
+
+
+def test_output_size_truncation_rule():
+    # PostProcessor.cpp:512-518: uint32 <- float truncation; <1 divides, >=1 multiplies
+    assert A.output_size(A.Config.default(render_scale=0.75), 1683, 1869) == (2244, 2492)
+    assert A.output_size(A.Config.default(render_scale=1.3), 2244, 2492) == (int(np.float32(2244) * np.float32(1.3)), int(np.float32(2492) * np.float32(1.3)))
+    assert A.output_size(A.Config.default(render_scale=1.3), 2244, 2492) == (2917, 3239)   # not 2916x3240
+    assert A.output_size(A.Config.default(render_scale=0.77), 1000, 1000) == (int(np.float32(1000) / np.float32(0.77)),) * 2
+    assert A.output_size(A.Config.default(render_scale=0.5, out_width=123, out_height=45), 10, 10) == (123, 45)
+
+
+def test_bad_struct_size_is_rejected():
+    cfg = A.Config.default()
+    cfg.struct_size = 12
+    w, h = C.c_uint32(), C.c_uint32()
+    assert A.library().ovrfsr_output_size(C.byref(cfg), 10, 10, C.byref(w), C.byref(h)) == 1
+    ctx = C.c_void_p()
+    assert A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx)) == 1 and not ctx
+
+
+def test_null_ctx_is_an_error_not_a_crash():
+    L = A.library()
+    assert L.ovrfsr_reset(None) == 1
+    assert L.ovrfsr_apply(None, 0, None, None, None, None) == 1
+    assert L.ovrfsr_last_error(None) == b"null ctx"
+    L.ovrfsr_destroy(None)
+
+
+def test_create_without_gpu_reports_no_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    cfg = A.Config.default(fsr_enabled=1)
+    assert A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx)) == 4   # OVRFSR_ERR_NO_DEVICE: no CPU fallback
+    with pytest.raises(K.OvrFsrError):
+        A.PostProcessor(fsr_enabled=1)

@@ -1,0 +1,129 @@
+"""Known-answer tests for the constant setup.  No GPU needed.
+
+Three implementations are checked against the committed outputs of the reference's own code
+(tests/golden/ref_consts.json, produced by tests/golden/make_golden.py from oracle/_ref):
+  * the product library's host code (ovrfsr_easu_con / ovrfsr_rcas_con / ovrfsr_nis_* via the C ABI),
+  * the oracle's C restatement,
+  * and, where oracle/_ref exists, the reference again (guards against a stale fixture).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import openvr_fsr_amd as A
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "ref_consts.json")))
+
+
+def u32(hexlist):
+    return np.array([int(h, 16) for h in hexlist], np.uint32)
+
+
+def test_survey_kats_easu():
+    # SURVEY.md 8c, captured from the compiled reference headers
+    con = A.easu_con(1683, 1869, 2244, 2492)
+    assert list(con[:4]) == [0x3f400000, 0x3f400000, 0xbe000000, 0xbe000000]
+    assert list(con[4:8]) == [0x3a1bc28c, 0x3a0c424b, 0x3a1bc28c, 0xba0c424b]
+    assert list(con[8:12]) == [0xba1bc28c, 0x3a8c424b, 0x3a1bc28c, 0x3a8c424b]
+    assert list(con[12:]) == [0, 0x3b0c424b, 0, 0]
+    con = A.easu_con(2244, 2492, 2916, 3240)
+    assert list(con[:4]) == [0x3f45010e, 0x3f44e616, 0xbdebfbc8, 0xbdec67a8]
+
+
+def test_survey_kats_rcas():
+    stops = float(np.float32(2.0) - np.float32(2.0) * np.float32(0.9))
+    assert abs(stops - 0.200000048) < 1e-9
+    con = A.rcas_con(stops)
+    assert list(con) == [0x3f5edc66, 0x3af63af6, 0, 0]
+
+
+@pytest.mark.parametrize("case", G["easu_con"], ids=lambda c: "%dx%d" % tuple(c["in"]))
+def test_easu_con_golden(case):
+    want = u32(case["con"])
+    iw, ih = case["in"]
+    ow, oh = case["out"]
+    assert np.array_equal(A.easu_con(iw, ih, ow, oh), want)
+    assert np.array_equal(O.easu_con(iw, ih, ow, oh), want)
+
+
+@pytest.mark.parametrize("case", G["rcas_con"], ids=lambda c: str(c["sharpness"]))
+def test_rcas_con_golden(case):
+    want = u32(case["con"])
+    stops = float(u32([case["stops_bits"]]).view(np.float32)[0])
+    assert np.array_equal(A.rcas_con(stops), want)
+    got = O.rcas_con(case["sharpness"])
+    assert np.array_equal(got, want)  # includes the clamp of sharpness to [0,1]
+
+
+def test_f32_to_f16_trunc_golden():
+    for bits, want in G["f32_to_f16"]:
+        f = float(u32([bits]).view(np.float32)[0])
+        assert O.lib().ovo_f32_to_f16_trunc(f) == int(want, 16), bits
+
+
+def test_mask_constants_kats():
+    # radius 0.5 -> r = uint(0.25*outH)
+    c, r = A.mask_constants(2244, 2492, (0.5, 0.5, 0.5, 0.5), 0.5, True, 0)
+    assert list(r) == [623, 388129, 2244, 2492] and list(c) == [1122, 1246, 1122, 1246]
+    c, r = A.mask_constants(3160, 3160, (0.5, 0.5, 0.5, 0.5), 0.5, True, 1)
+    assert list(r) == [790, 624100, 3160, 3160]
+    # shared side-by-side texture: integer outW/2 first (PostProcessor.cpp:298,300)
+    c, r = A.mask_constants(4489, 2492, (0.45, 0.5, 0.55, 0.52), 0.5, False, 0)
+    half = 4489 // 2
+    assert list(c) == [int(np.float32(half) * np.float32(0.45)), int(np.float32(2492) * np.float32(0.5)),
+                       int(np.float32(half) * (np.float32(1) + np.float32(0.55))), int(np.float32(2492) * np.float32(0.52))]
+    for args in [(2244, 2492, (0.37, 0.61, 0.58, 0.44), 0.73, True, 1), (1000, 900, (0.5, 0.5, 0.5, 0.5), 2.0, False, 0)]:
+        a = A.mask_constants(*args)
+        o = O.mask_constants(args[0], args[1], args[3], args[2], args[4], args[5])
+        assert np.array_equal(a[0], o[0]) and np.array_equal(a[1], o[1])
+
+
+@pytest.mark.parametrize("case", G["nis_scaler"], ids=lambda c: "%s-%dx%d" % (c["sharpness"], c["in"][0], c["out"][0]))
+def test_nis_scaler_config_golden(case):
+    ok, buf = A.nis_scaler_config(case["sharpness"], case["in"][0], case["in"][1], case["out"][0], case["out"][1])
+    assert int(ok) == case["ok"]
+    assert np.array_equal(buf, u32(case["cfg"]))  # all 256 bytes, including the half-filled failure case
+
+
+@pytest.mark.parametrize("case", G["nis_sharpen"], ids=lambda c: str(c["sharpness"]))
+def test_nis_sharpen_config_golden(case):
+    ok, buf = A.nis_sharpen_config(case["sharpness"], case["in"][0], case["in"][1])
+    assert int(ok) == case["ok"] and np.array_equal(buf, u32(case["cfg"]))
+
+
+def test_nis_config_survey_kat():
+    ok, buf = A.nis_scaler_config(0.9, 1683, 1869, 2244, 2492)
+    f = buf.view(np.float32)
+    assert ok and abs(f[0] - 1.10058594) < 1e-7 and f[1] == 0.0625 and f[2] == 2 and f[3] == 0.125
+    assert abs(f[9] - 1.31999993) < 1e-7 and f[12] == 0.75 and f[13] == 0.75
+    ok, _ = A.nis_scaler_config(0.9, 400, 400, 1000, 1000)  # scale 0.4 -> false
+    assert not ok
+
+
+def test_nis_coef_tables_golden():
+    s, u = A.nis_coefs()
+    assert np.array_equal(s.view(np.uint32).ravel(), u32(G["nis_coef_scale"]))
+    assert np.array_equal(u.view(np.uint32).ravel(), u32(G["nis_coef_usm"]))
+    assert (s[:, 6:] == 0).all() and (u[:, 6:] == 0).all()
+    np.testing.assert_allclose(s[:, :6].sum(1), 1.0, atol=2e-3)   # polyphase rows are DC-normalised
+    np.testing.assert_allclose(u[:, :6].sum(1), 0.0, atol=2e-3)   # USM rows are DC-free
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
+def test_fixture_is_fresh_against_reference():
+    R = O.ref()
+    for case in G["easu_con"]:
+        con = np.zeros(16, np.uint32)
+        iw, ih = case["in"]
+        ow, oh = case["out"]
+        R.ref_easu_con(con.ctypes.data_as(O.u32p), iw, ih, iw, ih, ow, oh)
+        assert np.array_equal(con, u32(case["con"]))
+    rng = np.random.default_rng(0)
+    for _ in range(2000):
+        f = float((rng.uniform(1, 2) * 2.0 ** rng.integers(-40, 30)) * rng.choice([-1, 1]))
+        f = float(np.float32(f))
+        assert O.lib().ovo_f32_to_f16_trunc(f) == R.ref_f32_to_f16(f)
