@@ -21,8 +21,13 @@ namespace ovrfsr_strict {
 
 namespace ovrfsr {
 
+// LDS row pitch (cells) of the product-build EASU kernel; 0 = footprint too wide, use the generic kernel
+int easu_fast_pitch(int cellsW) { return cellsW <= 32 ? 32 : cellsW <= 40 ? 40 : 0; }
+
 size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 {
+    if (prec != PREC_FP32_STRICT && easu_fast_pitch(cellsW) != 0)
+        return (size_t)easu_fast_pitch(cellsW) * cellsH * (16 + 16 + 4);
     const bool wide = (prec == PREC_FP32_STRICT) || (in_fmt == FMT_RGBA32F);
     const size_t ncell = (size_t)cellsW * cellsH;
     const size_t col = (ncell * (wide ? 16 : 8) + 15) & ~(size_t)15;
@@ -32,7 +37,10 @@ size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 template <int I, int O>
 static hipError_t easu_go(bool strict, const EasuArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
+    const int pitch = easu_fast_pitch(a.cellsW);
     if (strict) hipLaunchKernelGGL((ovrfsr_strict::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 40) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
     return hipGetLastError();
 }
@@ -40,7 +48,7 @@ template <int I, int O>
 static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t s)
 {
     if (strict) hipLaunchKernelGGL((ovrfsr_strict::rcas_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((ovrfsr_fast::rcas_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((ovrfsr_fast::rcas_fast_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

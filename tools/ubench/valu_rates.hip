@@ -104,6 +104,46 @@ KERNEL(k_lshrrev, V8_2("v_lshrrev_b32"))
 KERNEL(k_cvt_pkrtz, V8_2("v_cvt_pkrtz_f16_f32"))
 KERNEL(k_pk_add_f16, V8_2("v_pk_add_f16"))
 KERNEL(k_dot2_f32_f16, V8("v_dot2_f32_f16"))
+KERNEL(k_min_u32, V8_2("v_min_u32"))
+KERNEL(k_max_i32, V8_2("v_max_i32"))
+KERNEL(k_min3_u32, V8("v_min3_u32"))
+KERNEL(k_and_b32, V8_2("v_and_b32"))
+KERNEL(k_or_b32, V8_2("v_or_b32"))
+KERNEL(k_lshl_or_b32, V8("v_lshl_or_b32"))
+KERNEL(k_lshl_add_u32, V8("v_lshl_add_u32"))
+KERNEL(k_add3_u32, V8("v_add3_u32"))
+KERNEL(k_perm_b32, V8("v_perm_b32"))
+KERNEL(k_bfe_u32, V8("v_bfe_u32"))
+KERNEL(k_cvt_pk_u8_f32, V8("v_cvt_pk_u8_f32"))
+KERNEL(k_cvt_u32_f32, V8_1("v_cvt_u32_f32"))
+KERNEL(k_cvt_f32_u32, V8_1("v_cvt_f32_u32"))
+KERNEL(k_floor_f32, V8_1("v_floor_f32"))
+KERNEL(k_mov_b32, V8_1("v_mov_b32"))
+KERNEL(k_fmac_f32, V8_2("v_fmac_f32"))
+KERNEL(k_mul_u32_u24, V8_2("v_mul_u32_u24"))
+KERNEL(k_mad_u32_u24, V8("v_mad_u32_u24"))
+KERNEL(k_max_f32, V8_2("v_max_f32"))
+KERNEL(k_max3_f32, V8("v_max3_f32"))
+#define VCND8                                                                  \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a0) : "v"(b0) : "vcc"); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a1) : "v"(b1) : "vcc"); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a2) : "v"(b2) : "vcc"); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a3) : "v"(b3) : "vcc"); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a4) : "v"(b4) : "vcc"); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a5) : "v"(b5) : "vcc"); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a6) : "v"(b6) : "vcc"); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a7) : "v"(b7) : "vcc");
+KERNEL(k_cndmask, VCND8)
+#define VCMP8                                                        \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a0), "v"(b0) : "vcc"); \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a1), "v"(b1) : "vcc"); \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a2), "v"(b2) : "vcc"); \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a3), "v"(b3) : "vcc"); \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a4), "v"(b4) : "vcc"); \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a5), "v"(b5) : "vcc"); \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a6), "v"(b6) : "vcc"); \
+    asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a7), "v"(b7) : "vcc");
+KERNEL(k_cmp_lt_f32, VCMP8)
 PKERNEL(k_pk_fma_f32, P4("v_pk_fma_f32"))
 PKERNEL(k_pk_mul_f32, P4_2("v_pk_mul_f32"))
 PKERNEL(k_pk_add_f32, P4_2("v_pk_add_f32"))
@@ -137,6 +177,12 @@ LKERNEL(k_ds_read_b64, float2v, "ds_read_b64", 8)
 LKERNEL(k_ds_read_b128, float4v, "ds_read_b128", 16)
 LKERNEL(k_ds_read_b64_s6, float2v, "ds_read_b64", 6 * 8 / 8 * 8)   // stride 0.75-ish pattern approximated below
 
+
+__global__ void k_probe_cvt(float *out)
+{
+    const float vals[8] = {0.49f, 0.5f, 0.51f, 1.5f, 2.5f, 254.5f, 255.7f, -0.7f};
+    for (int i = 0; i < 8; ++i) { unsigned r = 0; asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(r) : "v"(vals[i])); out[i] = (float)r; }
+}
 typedef void (*kern_t)(float *, int, float);
 
 static double run(kern_t k, float *d, int iters, int blocks)
@@ -173,6 +219,12 @@ int main()
         {"v_cvt_f32_f16", k_cvt_f32_f16, 64}, {"v_cvt_f16_f32", k_cvt_f16_f32, 64}, {"v_cvt_pkrtz_f16_f32", k_cvt_pkrtz, 64},
         {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte0, 64},
         {"v_rcp_f32", k_rcp_f32, 64}, {"v_rcp_f16", k_rcp_f16, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_lshrrev_b32", k_lshrrev, 64},
+        {"v_min_u32", k_min_u32, 64}, {"v_max_i32", k_max_i32, 64}, {"v_min3_u32", k_min3_u32, 64}, {"v_max_f32", k_max_f32, 64}, {"v_max3_f32", k_max3_f32, 64},
+        {"v_and_b32", k_and_b32, 64}, {"v_or_b32", k_or_b32, 64}, {"v_lshl_or_b32", k_lshl_or_b32, 64}, {"v_lshl_add_u32", k_lshl_add_u32, 64},
+        {"v_add3_u32", k_add3_u32, 64}, {"v_perm_b32", k_perm_b32, 64}, {"v_bfe_u32", k_bfe_u32, 64}, {"v_cvt_pk_u8_f32", k_cvt_pk_u8_f32, 64},
+        {"v_cvt_u32_f32", k_cvt_u32_f32, 64}, {"v_cvt_f32_u32", k_cvt_f32_u32, 64}, {"v_floor_f32", k_floor_f32, 64}, {"v_mov_b32", k_mov_b32, 64},
+        {"v_fmac_f32", k_fmac_f32, 64}, {"v_mul_u32_u24", k_mul_u32_u24, 64}, {"v_mad_u32_u24", k_mad_u32_u24, 64},
+        {"v_cndmask_b32", k_cndmask, 64}, {"v_cmp_lt_f32", k_cmp_lt_f32, 64},
         {"ds_read_b32", k_ds_read_b32, 64}, {"ds_read_b64", k_ds_read_b64, 64}, {"ds_read_b128", k_ds_read_b128, 64},
     };
     const int iters = 4000;
@@ -183,6 +235,9 @@ int main()
         double cyc = ms * 1e-3 * ghz * 1e9 / instr_per_simd;
         printf("%-22s %8.3f ms  %6.2f cycles / wave-instruction / SIMD (at %.2f GHz nominal)\n", k.n, ms, cyc, ghz);
     }
+    hipLaunchKernelGGL(k_probe_cvt, dim3(1), dim3(1), 0, 0, d);
+    float h[8]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    printf("v_cvt_pk_u8_f32 of {0.49,0.5,0.51,1.5,2.5,254.5,255.7,-0.7} = %g %g %g %g %g %g %g %g\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     hipFree(d);
     return 0;
 }
