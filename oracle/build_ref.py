@@ -153,6 +153,9 @@ def gen_nis(ref):
     scaler = read(os.path.join(nis, "NIS_Scaler.h"))
 
     def nis_to_cpp(text):
+        # HLSL floating literals without a suffix are `float`; in C++ they would be `double` and drag whole
+        # expressions into double arithmetic.  Suffix them (comments/preprocessor integers are unaffected).
+        text = re.sub(r"(?<![\w.])((?:\d+\.\d*|\.\d+)(?:[eE][+-]?\d+)?)(?![\w.])", r"\1f", text)
         text = re.sub(r"\bgroupshared\b", "static", text)
         text = re.sub(r"#define\s+NIS_UNROLL\s+\[unroll\]", "#define NIS_UNROLL", text)
         # C++ needs the array-typed prototypes as they are; float4 casts `(NVF4)x` are fine.
@@ -161,7 +164,7 @@ def gen_nis(ref):
     def one(fname, ns):
         src = read(os.path.join(nis, fname))
         # each entry file #defines its own NIS_SCALER / block sizes before including the header
-        body = hlsl_entry_to_cpp(src, {"NIS_Scaler.h": nis_to_cpp(scaler)})
+        body = hlsl_entry_to_cpp(nis_to_cpp(src), {"NIS_Scaler.h": nis_to_cpp(scaler)})
         body = re.sub(r"\bTexture2D\s+(\w+)\s*;", r"Texture2D \1;", body)
         return "namespace %s {\n%s\n}\n" % (ns, body)
 

@@ -25,8 +25,9 @@
  *     i j k l(fx+2,fy+1) n(fx,fy+2) o(fx+1,fy+2)).
  *   - Texture2D.Load out of bounds returns 0 in every channel.
  *   - UNORM8 -> float is b/255 (correctly rounded); float -> UNORM8 is floor(sat(x)*255+0.5).
- *   - bilinear SampleLevel: texel-space coordinate u*W-0.5, clamp addressing, full fp32 weights
- *     (hardware uses >=8 fractional bits: the reference itself is only defined to ~1/256 here).
+ *   - bilinear SampleLevel: texel-space coordinate u*W-0.5 snapped to 8 fractional bits
+ *     (D3D11_SUBTEXEL_FRACTIONAL_BIT_COUNT; round to nearest), clamp addressing, weights from that
+ *     fixed-point fraction.  A sample at a texel centre therefore returns the texel exactly.
  *
  * Pinning status: bit-exact against the reference's own FsrEasuF/FsrRcasF/FsrEasuCon/FsrRcasCon
  * compiled for the CPU through oracle/hlsl_shim.hpp (oracle/_ref, see oracle/Makefile and
@@ -277,14 +278,25 @@ static void easu_pixel(float pix[3], int ipx, int ipy, const uint32_t con[16], c
     for (int ch = 0; ch < 3; ++ch) pix[ch] = fminf(mx[ch], fmaxf(mn[ch], aC[ch] * rW));
 }
 
+/* D3D11 fixed-point texel addressing: texel-space coordinate snapped to 8 fractional bits
+ * (D3D11_SUBTEXEL_FRACTIONAL_BIT_COUNT), round to nearest. */
+static inline void fixed8(float t, int *i0, float *frac)
+{
+    float s = floorf(t * 256.0f + 0.5f);
+    float f = floorf(s * (1.0f / 256.0f));
+    *i0 = (int)f;
+    *frac = (s - f * 256.0f) * (1.0f / 256.0f);
+}
+
 /* bilinear SampleLevel with linear/clamp sampler at normalised (u,v); fsr_easu.hlsl:33-36 */
 static void sample_bilinear(float out[4], const image_t *im, float u, float v)
 {
     float tx = u * (float)im->w - 0.5f;
     float ty = v * (float)im->h - 0.5f;
-    float x0f = floorf(tx), y0f = floorf(ty);
-    float fx = tx - x0f, fy = ty - y0f;
-    int x0 = (int)x0f, y0 = (int)y0f;
+    int x0, y0;
+    float fx, fy;
+    fixed8(tx, &x0, &fx);
+    fixed8(ty, &y0, &fy);
     const float *c00 = texel_clamp(im, x0, y0), *c10 = texel_clamp(im, x0 + 1, y0);
     const float *c01 = texel_clamp(im, x0, y0 + 1), *c11 = texel_clamp(im, x0 + 1, y0 + 1);
     float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy);

@@ -81,7 +81,7 @@ inline uint2::uint2(const int2 &i) : x((uint)i.x), y((uint)i.y) {}
 inline float2::float2(const uint2 &u) : x((float)u.x), y((float)u.y) {}
 inline float2::float2(const int2 &u) : x((float)u.x), y((float)u.y) {}
 struct uint3 {
-    uint x, y, z;
+    union { struct { uint x, y, z; }; Swz2<uint2, uint, 0, 1> xy; };
     uint3() : x(0), y(0), z(0) {}
     uint3(uint a, uint b, uint c) : x(a), y(b), z(c) {}
 };
@@ -196,12 +196,19 @@ struct Texture2D {
     float4 GatherRed(const SamplerState &, const float2 &uv, const int2 &) const { return gather(uv, 0); }
     float4 GatherGreen(const SamplerState &, const float2 &uv, const int2 &) const { return gather(uv, 1); }
     float4 GatherBlue(const SamplerState &, const float2 &uv, const int2 &) const { return gather(uv, 2); }
-    // bilinear, full-precision fp32 weights (hardware: >= 8 fractional bits)
+    // bilinear with D3D11's fixed-point texel addressing: the texel-space coordinate u*W-0.5 is
+    // snapped to D3D11_SUBTEXEL_FRACTIONAL_BIT_COUNT = 8 fractional bits (round to nearest) before the
+    // footprint and the weights are derived -- a sample at a texel centre returns that texel exactly.
+    static void fixed8(float t, int &i0, float &frac) {
+        float s = floorf(t * 256.0f + 0.5f);
+        float f = floorf(s * (1.0f / 256.0f));
+        i0 = (int)f;
+        frac = (s - f * 256.0f) * (1.0f / 256.0f);
+    }
     float4 SampleLevel(const SamplerState &, const float2 &uv, float) const {
         float tx = uv.x * (float)w - 0.5f, ty = uv.y * (float)h - 0.5f;
-        float x0f = floorf(tx), y0f = floorf(ty);
-        float fx = tx - x0f, fy = ty - y0f;
-        int x0 = (int)x0f, y0 = (int)y0f;
+        int x0, y0; float fx, fy;
+        fixed8(tx, x0, fx); fixed8(ty, y0, fy);
         float4 c00 = at_clamp(x0, y0), c10 = at_clamp(x0 + 1, y0);
         float4 c01 = at_clamp(x0, y0 + 1), c11 = at_clamp(x0 + 1, y0 + 1);
         float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy);

@@ -204,3 +204,92 @@ def ref_rcas(img, con, centre, radius):
     out = np.zeros((H, W, 4), np.float32)
     ref().ref_rcas_dispatch(_ptr(img, f32p), W, H, _ptr(out, f32p), _ptr(c, u32p))
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# NIS
+# ---------------------------------------------------------------------------------------------
+def _nis_lib():
+    L = lib()
+    if not getattr(L, "_nis_bound", False):
+        L.ovo_nis_upscale.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, C.c_void_p, f32p, f32p, C.c_int]
+        L.ovo_nis_upscale.restype = C.c_int
+        L.ovo_nis_sharpen.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_void_p, C.c_int]
+        L.ovo_nis_sharpen.restype = C.c_int
+        L._nis_bound = True
+    return L
+
+
+def nis_block(cfg_words, centre, radius, debug=0):
+    """NISConfig as PostProcessor.cpp:308-310 uploads it: reserved1 = debug (float), centre/radius at byte 112."""
+    blk = np.array(cfg_words, np.uint32).copy()
+    blk[27] = np.array([1.0 if debug else 0.0], np.float32).view(np.uint32)[0]
+    blk[28:32] = centre
+    blk[32:36] = radius
+    return blk
+
+
+def nis_upscale(img, outW, outH, blk, coef_scale, coef_usm, nthreads=0):
+    img = np.ascontiguousarray(img, np.float32)
+    inH, inW = img.shape[:2]
+    out = np.empty((outH, outW, 4), np.float32)
+    cs, cu = np.ascontiguousarray(coef_scale, np.float32), np.ascontiguousarray(coef_usm, np.float32)
+    blk = np.ascontiguousarray(blk, np.uint32)
+    nt = nthreads or lib().ovo_max_threads()
+    rc = _nis_lib().ovo_nis_upscale(_ptr(img, f32p), inW, inH, _ptr(out, f32p), outW, outH, blk.ctypes.data,
+                                    _ptr(cs, f32p), _ptr(cu, f32p), nt)
+    assert rc == 0
+    return out
+
+
+def nis_sharpen(img, blk, nthreads=0):
+    img = np.ascontiguousarray(img, np.float32)
+    H, W = img.shape[:2]
+    out = np.empty((H, W, 4), np.float32)
+    blk = np.ascontiguousarray(blk, np.uint32)
+    nt = nthreads or lib().ovo_max_threads()
+    rc = _nis_lib().ovo_nis_sharpen(_ptr(img, f32p), W, H, _ptr(out, f32p), blk.ctypes.data, nt)
+    assert rc == 0
+    return out
+
+
+def _ref_nis():
+    R = ref()
+    if not getattr(R, "_nis_bound", False):
+        R.ref_nis_upscale_dispatch.argtypes = [f32p, C.c_int, C.c_int, f32p, C.c_int, C.c_int, u32p, f32p, f32p]
+        R.ref_nis_sharpen_dispatch.argtypes = [f32p, C.c_int, C.c_int, f32p, u32p, f32p, f32p]
+        R._nis_bound = True
+    return R
+
+
+def ref_nis_coefs():
+    sc, us = np.zeros(512, np.float32), np.zeros(512, np.float32)
+    ref().ref_nis_coefs(_ptr(sc, f32p), _ptr(us, f32p))
+    return sc.reshape(64, 8), us.reshape(64, 8)
+
+
+def ref_nis_scaler_config(sharpness, inW, inH, outW, outH):
+    buf = np.zeros(64, np.uint32)
+    ok = ref().ref_nis_scaler_config(buf.ctypes.data, sharpness, inW, inH, outW, outH)
+    return bool(ok), buf
+
+
+def ref_nis_upscale(img, outW, outH, blk, coef_scale, coef_usm):
+    img = np.ascontiguousarray(img, np.float32)
+    inH, inW = img.shape[:2]
+    out = np.zeros((outH, outW, 4), np.float32)
+    cs, cu = np.ascontiguousarray(coef_scale, np.float32), np.ascontiguousarray(coef_usm, np.float32)
+    blk = np.ascontiguousarray(blk, np.uint32)
+    _ref_nis().ref_nis_upscale_dispatch(_ptr(img, f32p), inW, inH, _ptr(out, f32p), outW, outH, _ptr(blk, u32p),
+                                        _ptr(cs, f32p), _ptr(cu, f32p))
+    return out
+
+
+def ref_nis_sharpen(img, blk, coef_scale, coef_usm):
+    img = np.ascontiguousarray(img, np.float32)
+    H, W = img.shape[:2]
+    out = np.zeros((H, W, 4), np.float32)
+    cs, cu = np.ascontiguousarray(coef_scale, np.float32), np.ascontiguousarray(coef_usm, np.float32)
+    blk = np.ascontiguousarray(blk, np.uint32)
+    _ref_nis().ref_nis_sharpen_dispatch(_ptr(img, f32p), W, H, _ptr(out, f32p), _ptr(blk, u32p), _ptr(cs, f32p), _ptr(cu, f32p))
+    return out

@@ -5,6 +5,7 @@ Needs oracle/_ref/libovrfsr_ref.so (python oracle/build_ref.py, only possible wh
 exists).  Everything written here is an output of reference code:
   ref_consts.json  FsrEasuCon / FsrRcasCon / f32->f16 / NVScalerUpdateConfig / coefficient banks
                    (compiled with #define A_CPU exactly as PostProcessor.cpp:7-11 does)
+  nis_vectors.npz  the same for nis/NIS_Scaler.h (NVScaler, NVSharpen, DirectCopy, radius mask)
   fsr_vectors.npz  small RGBA8 inputs and the float outputs of the reference's own fsr_easu.hlsl /
                    fsr_rcas.hlsl entry points (FsrEasuF / FsrRcasF bodies + radius mask) compiled
                    through oracle/hlsl_shim.hpp
@@ -106,9 +107,44 @@ def vectors():
     np.savez_compressed(os.path.join(HERE, "fsr_vectors.npz"), **data)
 
 
+NIS_CASES = [
+    # name, inW, inH, outW, outH, generator, seed, radius, proj, eye, sharpness, debug
+    ("nis_structured", 48, 40, 64, 53, "structured_u8", 11, 2.0, (0.5, 0.5, 0.5, 0.5), 0, 0.9, 0),
+    ("nis_random_mask", 61, 47, 80, 63, "random_u8", 12, 0.5, (0.45, 0.55, 0.6, 0.4), 1, 0.5, 1),
+    ("nis_extremes_2x", 30, 26, 60, 52, "extremes_u8", 13, 0.8, (0.5, 0.5, 0.5, 0.5), 0, 0.2, 0),
+]
+
+
+def nis_vectors():
+    """Outputs of the reference's own NIS_Scaler.h (NVScaler / NVSharpen + DirectCopy + mask) via oracle/_ref."""
+    cs, cu = O.ref_nis_coefs()
+    data, meta = {}, []
+    for (name, iw, ih, ow, oh, gen, seed, radius, proj, eye, sharp, dbg) in NIS_CASES:
+        img8 = getattr(synth, gen)(iw, ih, seed)
+        ok, cfg = O.ref_nis_scaler_config(sharp, iw, ih, ow, oh)
+        centre, rad = O.mask_constants(ow, oh, radius, proj, True, eye)
+        blk = O.nis_block(cfg, centre, rad, dbg)
+        up = O.ref_nis_upscale(O.unorm8_to_float(img8), ow, oh, blk, cs, cu)
+        # sharpen-only (renderScale == 1) on the same input
+        ok2, cfg2 = O.ref_nis_scaler_config(sharp, iw, ih, iw, ih)
+        c2, r2 = O.mask_constants(iw, ih, radius, proj, True, eye)
+        blk2 = O.nis_block(cfg2, c2, r2, dbg)
+        sh = O.ref_nis_sharpen(O.unorm8_to_float(img8), blk2, cs, cu)
+        data[name + "_in"] = img8
+        data[name + "_upscale"] = up
+        data[name + "_sharpen"] = sh
+        data[name + "_blk_upscale"] = blk
+        data[name + "_blk_sharpen"] = blk2
+        meta.append({"name": name, "in": [iw, ih], "out": [ow, oh], "radius": radius, "proj": list(proj), "eye": eye,
+                     "sharpness": sharp, "debug": dbg, "ok": int(ok)})
+    data["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "nis_vectors.npz"), **data)
+
+
 if __name__ == "__main__":
     if not O.have_ref():
         sys.exit("oracle/_ref missing: run python oracle/build_ref.py where /root/reference exists")
     consts()
     vectors()
+    nis_vectors()
     print("golden fixtures written")

@@ -1,0 +1,76 @@
+"""The NIS CPU oracle (oracle/nis_oracle.c) against the reference's own NIS_Scaler.h.  No GPU needed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import openvr_fsr_amd as A
+from oracle import oracle as O
+from tests import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+V = np.load(os.path.join(HERE, "golden", "nis_vectors.npz"))
+META = json.loads(bytes(V["meta"]).decode())
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("m", META, ids=lambda m: m["name"])
+def test_nis_oracle_matches_golden(m):
+    name = m["name"]
+    img = O.unorm8_to_float(V[name + "_in"])
+    cs, cu = A.nis_coefs()            # the product's committed tables (checked against the reference elsewhere)
+    ow, oh = m["out"]
+    # the constant block is rebuilt by the PRODUCT's host code and must equal what the reference uploaded
+    ok, cfg = A.nis_scaler_config(m["sharpness"], m["in"][0], m["in"][1], ow, oh)
+    centre, rad = O.mask_constants(ow, oh, m["radius"], m["proj"], True, m["eye"])
+    blk = O.nis_block(cfg, centre, rad, m["debug"])
+    assert np.array_equal(blk, V[name + "_blk_upscale"])
+    assert same_bits(O.nis_upscale(img, ow, oh, blk, cs, cu), V[name + "_upscale"])
+    ok2, cfg2 = A.nis_sharpen_config(m["sharpness"], m["in"][0], m["in"][1])
+    c2, r2 = O.mask_constants(m["in"][0], m["in"][1], m["radius"], m["proj"], True, m["eye"])
+    blk2 = O.nis_block(cfg2, c2, r2, m["debug"])
+    assert np.array_equal(blk2, V[name + "_blk_sharpen"])
+    assert same_bits(O.nis_sharpen(img, blk2), V[name + "_sharpen"])
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
+@pytest.mark.parametrize("seed", range(5))
+def test_nis_oracle_matches_reference_random(seed):
+    rng = np.random.default_rng(100 + seed)
+    cs, cu = O.ref_nis_coefs()
+    w, h = int(rng.integers(16, 90)), int(rng.integers(16, 90))
+    gen = [synth.structured_u8, synth.random_u8, synth.extremes_u8][seed % 3]
+    src = O.unorm8_to_float(gen(w, h, seed))
+    sharp = float(rng.uniform(0, 1))
+    s = rng.uniform(0.5, 1.0)
+    ow, oh = int(w / s), int(h / s)
+    ok, cfg = O.ref_nis_scaler_config(sharp, w, h, ow, oh)
+    assert ok
+    centre, rad = O.mask_constants(ow, oh, float(rng.uniform(0.3, 1.5)), tuple(rng.uniform(0.3, 0.7, 4)), True, seed & 1)
+    blk = O.nis_block(cfg, centre, rad, seed & 1)
+    assert same_bits(O.nis_upscale(src, ow, oh, blk, cs, cu), O.ref_nis_upscale(src, ow, oh, blk, cs, cu))
+    ok, cfg = O.ref_nis_scaler_config(sharp, w, h, w, h)
+    centre, rad = O.mask_constants(w, h, float(rng.uniform(0.3, 1.5)), tuple(rng.uniform(0.3, 0.7, 4)), True, seed & 1)
+    blk = O.nis_block(cfg, centre, rad, seed & 1)
+    assert same_bits(O.nis_sharpen(src, blk), O.ref_nis_sharpen(src, blk, cs, cu))
+
+
+def test_nis_invariants():
+    cs, cu = A.nis_coefs()
+    w, h, ow, oh = 40, 30, 60, 45
+    ok, cfg = A.nis_scaler_config(0.9, w, h, ow, oh)
+    centre, rad = O.mask_constants(ow, oh, 2.0)
+    blk = O.nis_block(cfg, centre, rad)
+    # constant image is a fixed point (polyphase rows sum to 1, USM rows to 0, edge maps all zero)
+    const = np.empty((h, w, 4), np.float32)
+    const[...] = np.array([0.25, 0.5, 0.75, 1.0], np.float32)
+    out = O.nis_upscale(const, ow, oh, blk, cs, cu)
+    np.testing.assert_allclose(out, np.broadcast_to(const[0, 0], out.shape), atol=3e-3)
+    # outputs are clamped to [0,1] by the unorm UAV; alpha is the sampled alpha
+    img = O.unorm8_to_float(synth.extremes_u8(w, h, 2))
+    out = O.nis_upscale(img, ow, oh, blk, cs, cu)
+    assert out.min() >= 0.0 and out.max() <= 1.0 and (out[..., 3] == 1.0).all()
