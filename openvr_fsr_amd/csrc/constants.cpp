@@ -78,14 +78,15 @@ void mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t outW, uint3
     radius[3] = outH;
 }
 
-// Which branch do the 16x16 groups of an outW x outH dispatch take (fsr_easu.hlsl:41-45)?
-uint32_t classify_mask(const uint32_t c[4], uint32_t r2, uint32_t outW, uint32_t outH)
+// Which branch do the gw x gh groups of an outW x outH dispatch take?  FSR: 16x16 groups, centre +8
+// (fsr_easu.hlsl:41-45); NVScaler 32x24, centre +16,+12 (NIS_Upscale.hlsl:98); NVSharpen 32x32 (NIS_Sharpen.hlsl:96).
+uint32_t classify_mask(const uint32_t c[4], uint32_t r2, uint32_t outW, uint32_t outH, uint32_t gw, uint32_t gh)
 {
-    const uint32_t gxN = (outW + 15u) >> 4, gyN = (outH + 15u) >> 4;
+    const uint32_t gxN = (outW + gw - 1) / gw, gyN = (outH + gh - 1) / gh;
     bool anyIn = false, anyOut = false;
     for (uint32_t gy = 0; gy < gyN; ++gy)
         for (uint32_t gx = 0; gx < gxN; ++gx) {
-            const uint32_t cx = (gx << 4) + 8u, cy = (gy << 4) + 8u;
+            const uint32_t cx = gx * gw + gw / 2, cy = gy * gh + gh / 2;
             const uint32_t ax = c[0] - cx, ay = c[1] - cy, bx = c[2] - cx, by = c[3] - cy;
             const bool in = (ax * ax + ay * ay <= r2) || (bx * bx + by * by <= r2);
             anyIn |= in;

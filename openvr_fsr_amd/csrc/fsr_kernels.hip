@@ -7,6 +7,7 @@
 namespace ovrfsr_fast {
 #define OVRFSR_STRICT 0
 #pragma clang fp contract(fast)
+#include "fsr_device.inc"
 #include "fsr_kernels.inc"
 #undef OVRFSR_STRICT
 } // namespace ovrfsr_fast
@@ -14,6 +15,7 @@ namespace ovrfsr_fast {
 namespace ovrfsr_strict {
 #define OVRFSR_STRICT 1
 #pragma clang fp contract(off)
+#include "fsr_device.inc"
 #include "fsr_kernels.inc"
 #undef OVRFSR_STRICT
 } // namespace ovrfsr_strict

@@ -8,4 +8,8 @@ namespace ovrfsr {
 size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH);
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s);
 hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uint32_t batch, hipStream_t s);
+int nis_pitch(int cellsW);
+size_t nis_scaler_lds_bytes(int cellsW, int cellsH);
+hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s);
+hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s);
 } // namespace ovrfsr

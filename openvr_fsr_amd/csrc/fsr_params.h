@@ -61,4 +61,19 @@ struct FusedArgs {
     uint32_t quantize;      // 1: EASU result rounded to UNORM8 before RCAS (reference-faithful)
 };
 
+struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) minus the unused viewport fields
+    BatchView v;
+    float kDetectRatio, kDetectThres, kMinContrastRatio, kRatioNorm;
+    float kContrastBoost, kEps, kSharpStartY, kSharpScaleY;
+    float kSharpStrengthMin, kSharpStrengthScale, kSharpLimitMin, kSharpLimitScale;
+    float kScaleX, kScaleY, kDstNormX, kDstNormY;
+    float kSrcNormX, kSrcNormY;
+    float reserved1;        // debugMode as float (PostProcessor.cpp:309)
+    MaskArgs m;
+    const float *coefScale; // device copies of coef_scale / coef_usm, [64][8]
+    const float *coefUsm;
+    int32_t cellsW, cellsH; // LDS luma/edge tile extent of the scaler (incl. 3-texel ring)
+    uint32_t tilesX, tilesY;
+};
+
 } // namespace ovrfsr

@@ -1,0 +1,80 @@
+// nis_kernels.hip -- instantiates the gfx950 NIS kernels (product + strict builds) and their launchers.
+#include <hip/hip_runtime.h>
+#include "fsr_params.h"
+#include "fsr_launch.h"
+
+namespace ovrfsr_fast {
+#define OVRFSR_STRICT 0
+#pragma clang fp contract(fast)
+#include "fsr_device.inc"
+#include "nis_kernels.inc"
+#undef OVRFSR_STRICT
+} // namespace ovrfsr_fast
+
+namespace ovrfsr_strict {
+#define OVRFSR_STRICT 1
+#pragma clang fp contract(off)
+#include "fsr_device.inc"
+#include "nis_kernels.inc"
+#undef OVRFSR_STRICT
+} // namespace ovrfsr_strict
+#pragma clang fp contract(on)
+
+namespace ovrfsr {
+
+int nis_pitch(int cellsW) { return cellsW <= 32 ? 32 : cellsW <= 40 ? 40 : 0; }
+size_t nis_scaler_lds_bytes(int cellsW, int cellsH) { return (size_t)nis_pitch(cellsW) * cellsH * (4 + 4 + 16) + 2 * 512 * 4; }
+
+template <int I, int O>
+static hipError_t scaler_go(bool strict, const NisArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    const int pitch = nis_pitch(a.cellsW);
+    if (pitch == 32) {
+        if (strict) hipLaunchKernelGGL((ovrfsr_strict::nis_scaler_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, a);
+        else hipLaunchKernelGGL((ovrfsr_fast::nis_scaler_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, a);
+    } else if (pitch == 40) {
+        if (strict) hipLaunchKernelGGL((ovrfsr_strict::nis_scaler_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, a);
+        else hipLaunchKernelGGL((ovrfsr_fast::nis_scaler_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+template <int I, int O>
+static hipError_t sharpen_go(bool strict, const NisArgs &a, dim3 grid, hipStream_t s)
+{
+    if (strict) hipLaunchKernelGGL((ovrfsr_strict::nis_sharpen_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((ovrfsr_fast::nis_sharpen_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+#define OVRFSR_DISPATCH_FMT(FN, ...)                                                                     \
+    switch (in_fmt * 3 + out_fmt) {                                                                      \
+    case 0: return FN<FMT_RGBA8, FMT_RGBA8>(__VA_ARGS__);                                                \
+    case 1: return FN<FMT_RGBA8, FMT_RGBA16F>(__VA_ARGS__);                                              \
+    case 2: return FN<FMT_RGBA8, FMT_RGBA32F>(__VA_ARGS__);                                              \
+    case 3: return FN<FMT_RGBA16F, FMT_RGBA8>(__VA_ARGS__);                                              \
+    case 4: return FN<FMT_RGBA16F, FMT_RGBA16F>(__VA_ARGS__);                                            \
+    case 5: return FN<FMT_RGBA16F, FMT_RGBA32F>(__VA_ARGS__);                                            \
+    case 6: return FN<FMT_RGBA32F, FMT_RGBA8>(__VA_ARGS__);                                              \
+    case 7: return FN<FMT_RGBA32F, FMT_RGBA16F>(__VA_ARGS__);                                            \
+    case 8: return FN<FMT_RGBA32F, FMT_RGBA32F>(__VA_ARGS__);                                            \
+    default: return hipErrorInvalidValue;                                                                \
+    }
+
+hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s)
+{
+    if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
+    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    const size_t lds = nis_scaler_lds_bytes(a.cellsW, a.cellsH);
+    OVRFSR_DISPATCH_FMT(scaler_go, prec == PREC_FP32_STRICT, a, grid, lds, s)
+}
+
+hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s)
+{
+    if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
+    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    OVRFSR_DISPATCH_FMT(sharpen_go, prec == PREC_FP32_STRICT, a, grid, s)
+}
+
+} // namespace ovrfsr

@@ -41,6 +41,8 @@ void PostProcessor::Reset()
     initialized_ = false;
     if (upscaled_) (void)hipFree(upscaled_);
     if (sharpened_) (void)hipFree(sharpened_);
+    if (nisCoefDev_) (void)hipFree(nisCoefDev_);
+    nisCoefDev_ = nullptr;
     upscaled_ = sharpened_ = nullptr;
     upscaledBytes_ = sharpenedBytes_ = 0;
     lastSubmittedTexture_ = nullptr;
@@ -139,26 +141,76 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
     if (cfg_.stage_mask < 0 || cfg_.stage_mask > 2) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "bad stage_mask");
     if (!doUpscale_ && (ow != in.width || oh != in.height))
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "sharpen-only needs output size == input size");
-    if (cfg_.use_nis) return Fail(OVRFSR_ERR_UNSUPPORTED, "NIS path not built yet");
     if (cfg_.precision != OVRFSR_PRECISION_FP32 && cfg_.precision != OVRFSR_PRECISION_FP32_STRICT)
         return Fail(OVRFSR_ERR_UNSUPPORTED, "precision not built yet");
 
     for (int eye = 0; eye < 2; ++eye) {
         mask_constants(centre_[eye], radius_, ow, oh, cfg_.proj_centre, cfg_.radius, textureContainsOnlyOneEye_ ? 1 : 0, eye);
-        maskMode_[eye] = classify_mask(centre_[eye], radius_[1], ow, oh);
+        const uint32_t gw = cfg_.use_nis ? 32u : 16u, gh = cfg_.use_nis ? (scaleNotOne ? 24u : 32u) : 16u;
+        maskMode_[eye] = classify_mask(centre_[eye], radius_[1], ow, oh, gw, gh);
     }
-    if (doUpscale_) {
+    if (cfg_.use_nis) {
+        int rc = PrepareNisResources();
+        if (rc != OVRFSR_OK) return rc;
+    } else if (doUpscale_) {
         PrepareUpscalingResources();
         const size_t lds = easu_lds_bytes(cfg_.precision, (int)in.format, cellsW_, cellsH_);
         if (lds > 64 * 1024) return Fail(OVRFSR_ERR_UNSUPPORTED, "scale ratio needs more LDS than one tile may use");
     }
-    if (doSharpen_) PrepareSharpeningResources();
+    if (doSharpen_ && !cfg_.use_nis) PrepareSharpeningResources();
     if (cfg_.debug_mode && !evStart_) {
         if (hipEventCreate(&evStart_) != hipSuccess || hipEventCreate(&evEnd_) != hipSuccess)
             return Fail(OVRFSR_ERR_HIP, "hipEventCreate failed");
     }
     initialized_ = true;
     return OVRFSR_OK;
+}
+
+int PostProcessor::PrepareNisResources()
+{
+    std::memset(&nisConfig_, 0, sizeof(nisConfig_));
+    // NVScalerUpdateConfig (scale != 1) or NVSharpenUpdateConfig (out == in), PostProcessor.cpp:308,:433.
+    // The reference ignores a `false` result and dispatches with a half-filled block; that is undefined
+    // there, so it is an error here.
+    if (!nis_scaler_config(&nisConfig_, cfg_.sharpness, inputWidth_, inputHeight_, outputWidth_, outputHeight_))
+        return Fail(OVRFSR_ERR_UNSUPPORTED, "NIS scales 1x..2x only (NVScalerUpdateConfig returned false)");
+    nisConfig_.reserved1 = cfg_.debug_mode ? 1.f : 0.f; // :309
+    if (doUpscale_) {
+        auto extent = [](uint32_t outN, int blk, float s) {
+            int best = 0;
+            for (uint32_t o0 = 0; o0 < outN; o0 += blk) {
+                uint32_t o1 = o0 + blk - 1 < outN ? o0 + blk - 1 : outN - 1;
+                int f0 = (int)std::floor(mad2(0.5f + (float)o0, s, -0.5f)), f1 = (int)std::floor(mad2(0.5f + (float)o1, s, -0.5f));
+                best = f1 - f0 + 7 > best ? f1 - f0 + 7 : best; // 6-tap support (+2/+3) and the edge-map ring (+1)
+            }
+            return best;
+        };
+        nisCellsW_ = extent(outputWidth_, 32, nisConfig_.kScaleX);
+        nisCellsH_ = extent(outputHeight_, 24, nisConfig_.kScaleY);
+        if (nis_pitch(nisCellsW_) == 0 || nis_scaler_lds_bytes(nisCellsW_, nisCellsH_) > 64 * 1024)
+            return Fail(OVRFSR_ERR_UNSUPPORTED, "NIS tile does not fit LDS");
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&nisCoefDev_), 2 * 512 * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(nisCoefDev_, nis_coef_scale(), 512 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(nisCoefDev_ + 512, nis_coef_usm(), 512 * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("NIS coefficient upload: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
+}
+
+void PostProcessor::FillNis(NisArgs &a, int firstEye, int alternate) const
+{
+    const NisConstants &c = nisConfig_;
+    a.kDetectRatio = c.kDetectRatio; a.kDetectThres = c.kDetectThres; a.kMinContrastRatio = c.kMinContrastRatio; a.kRatioNorm = c.kRatioNorm;
+    a.kContrastBoost = c.kContrastBoost; a.kEps = c.kEps; a.kSharpStartY = c.kSharpStartY; a.kSharpScaleY = c.kSharpScaleY;
+    a.kSharpStrengthMin = c.kSharpStrengthMin; a.kSharpStrengthScale = c.kSharpStrengthScale;
+    a.kSharpLimitMin = c.kSharpLimitMin; a.kSharpLimitScale = c.kSharpLimitScale;
+    a.kScaleX = c.kScaleX; a.kScaleY = c.kScaleY; a.kDstNormX = c.kDstNormX; a.kDstNormY = c.kDstNormY;
+    a.kSrcNormX = c.kSrcNormX; a.kSrcNormY = c.kSrcNormY;
+    a.reserved1 = c.reserved1;
+    FillMask(a.m, firstEye, alternate);
+    a.coefScale = nisCoefDev_;
+    a.coefUsm = nisCoefDev_ + 512;
+    a.cellsW = nisCellsW_; a.cellsH = nisCellsH_;
 }
 
 void PostProcessor::FillMask(MaskArgs &m, int firstEye, int alternate) const
@@ -188,6 +240,16 @@ static BatchView make_view(const ovrfsr_image &in, size_t inStride, const ovrfsr
 int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                                   const ovrfsr_image &out, size_t outStride, hipStream_t stream)
 {
+    if (cfg_.use_nis) {
+        NisArgs na;
+        na.v = make_view(in, inStride, out, outStride);
+        FillNis(na, firstEye, alternate);
+        na.tilesX = (out.width + 31) / 32;   // Dispatch(ceil(outW/32), ceil(outH/24)), :397
+        na.tilesY = (out.height + 23) / 24;
+        hipError_t e = launch_nis_scaler(cfg_.precision, (int)in.format, (int)out.format, na, n, stream);
+        if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("NVScaler launch: ") + hipGetErrorString(e));
+        return OVRFSR_OK;
+    }
     EasuArgs a;
     a.v = make_view(in, inStride, out, outStride);
     std::memcpy(&a.sx, &easuCon_[0], 4); std::memcpy(&a.sy, &easuCon_[1], 4);
@@ -204,6 +266,16 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
 int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                                    const ovrfsr_image &out, size_t outStride, hipStream_t stream)
 {
+    if (cfg_.use_nis) {
+        NisArgs na;
+        na.v = make_view(in, inStride, out, outStride);
+        FillNis(na, firstEye, alternate);
+        na.tilesX = (out.width + 31) / 32;   // Dispatch(ceil(outW/32), ceil(outH/32)), :492
+        na.tilesY = (out.height + 31) / 32;
+        hipError_t e = launch_nis_sharpen(cfg_.precision, (int)in.format, (int)out.format, na, n, stream);
+        if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("NVSharpen launch: ") + hipGetErrorString(e));
+        return OVRFSR_OK;
+    }
     RcasArgs a;
     a.v = make_view(in, inStride, out, outStride);
     std::memcpy(&a.sharp, &rcasCon_[0], 4);

@@ -7,6 +7,7 @@
 #include <string>
 #include "../../include/openvr_fsr_amd.h"
 #include "fsr_params.h"
+#include "nis_tables.h"
 
 namespace ovrfsr {
 
@@ -15,7 +16,7 @@ void easu_con(uint32_t con[16], float inVpW, float inVpH, float inW, float inH, 
 void rcas_con(uint32_t con[4], float stops);
 void mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t outW, uint32_t outH, const float proj[4],
                     float cfgRadius, int onlyOneEye, int eye);
-uint32_t classify_mask(const uint32_t centre[4], uint32_t r2, uint32_t outW, uint32_t outH);
+uint32_t classify_mask(const uint32_t centre[4], uint32_t r2, uint32_t outW, uint32_t outH, uint32_t gw, uint32_t gh);
 
 class PostProcessor {
 public:
@@ -59,6 +60,10 @@ private:
     uint32_t radius_[4] = {};
     uint32_t maskMode_[2] = {};
     int cellsW_ = 0, cellsH_ = 0;
+    // NIS: the 256-byte NISConfig (PostProcessor.cpp:307-310) and the coefficient "textures" (:366-381)
+    NisConstants nisConfig_ = {};
+    float *nisCoefDev_ = nullptr; // coef_scale[512] | coef_usm[512]
+    int nisCellsW_ = 0, nisCellsH_ = 0;
 
     // ctx-owned device buffers: upscaledTexture / sharpenedTexture, PostProcessor.h:43-45,58-59
     void *upscaled_ = nullptr;
@@ -75,6 +80,8 @@ private:
     int PrepareResources(const ovrfsr_image &in);                         // :498-561
     void PrepareUpscalingResources();                                    // :285-383
     void PrepareSharpeningResources();                                   // :409-481
+    int PrepareNisResources();                                           // :307-310, :366-382, :432-435
+    void FillNis(NisArgs &a, int firstEye, int alternate) const;
     int EnsureBuffer(void **buf, size_t *have, size_t need);
     uint32_t IntermediateFormat() const;
     int ApplyPostProcess(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,

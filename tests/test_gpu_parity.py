@@ -144,3 +144,79 @@ def test_batch_matches_single(gpu):
         want = O.fsr_pipeline_u8(imgs[i], ow, oh, sharpness=0.9, radius=0.6, proj=proj, eye=i & 1)
         mx, frac = lsb_stats(got[i], want)
         assert mx <= RCAS_LSB and frac <= LSB_FRACTION, (i, mx, frac)
+
+
+# ------------------------------------------------------------------------------------------------
+# NIS (NVScaler, NVSharpen)
+# ------------------------------------------------------------------------------------------------
+def _nis_oracle_upscale(img8, ow, oh, sharpness, radius=2.0, proj=(0.5, 0.5, 0.5, 0.5), eye=0, debug=0):
+    import openvr_fsr_amd as A
+    ih, iw = img8.shape[:2]
+    cs, cu = A.nis_coefs()
+    ok, cfg = A.nis_scaler_config(sharpness, iw, ih, ow, oh)
+    assert ok
+    centre, rad = O.mask_constants(ow, oh, radius, proj, True, eye)
+    return O.nis_upscale(O.unorm8_to_float(img8), ow, oh, O.nis_block(cfg, centre, rad, debug), cs, cu)
+
+
+def _nis_oracle_sharpen(img8, sharpness, radius=2.0, proj=(0.5, 0.5, 0.5, 0.5), eye=0, debug=0):
+    import openvr_fsr_amd as A
+    h, w = img8.shape[:2]
+    ok, cfg = A.nis_sharpen_config(sharpness, w, h)
+    centre, rad = O.mask_constants(w, h, radius, proj, True, eye)
+    return O.nis_sharpen(O.unorm8_to_float(img8), O.nis_block(cfg, centre, rad, debug))
+
+
+NIS_SHAPES = [(96, 80, 128, 107, synth.structured_u8), (61, 47, 80, 63, synth.random_u8), (64, 64, 83, 83, synth.extremes_u8),
+              (50, 40, 100, 80, synth.structured_u8), (40, 33, 41, 34, synth.random_u8), (200, 120, 260, 156, synth.structured_u8)]
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh,gen", NIS_SHAPES)
+def test_nis_scaler_strict_bit_exact(gpu, iw, ih, ow, oh, gen):
+    img8 = gen(iw, ih, 21)
+    want = _nis_oracle_upscale(img8, ow, oh, 0.9)
+    got = run_gpu(img8, ow, oh, np.float32, precision=STRICT, use_nis=1, sharpness=0.9)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "max abs diff %g" % np.abs(got - want).max()
+    got8 = run_gpu(img8, ow, oh, np.uint8, precision=STRICT, use_nis=1, sharpness=0.9)
+    assert np.array_equal(got8, O.float_to_unorm8(want))
+
+
+@pytest.mark.parametrize("radius,proj,eye,debug,sharp", [(0.5, (0.5, 0.5, 0.5, 0.5), 0, 0, 0.5), (0.7, (0.42, 0.55, 0.61, 0.47), 1, 1, 0.2)])
+def test_nis_scaler_masked_strict_bit_exact(gpu, radius, proj, eye, debug, sharp):
+    iw, ih, ow, oh = 150, 120, 200, 160
+    img8 = synth.structured_u8(iw, ih, 5)
+    want = _nis_oracle_upscale(img8, ow, oh, sharp, radius, proj, eye, debug)
+    got = run_gpu(img8, ow, oh, np.float32, eye=eye, precision=STRICT, use_nis=1, sharpness=sharp, radius=radius,
+                  proj_centre=proj, debug_mode=debug)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "max abs diff %g" % np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("w,h,gen,radius,debug", [(128, 107, synth.structured_u8, 2.0, 0), (83, 83, synth.extremes_u8, 0.6, 1),
+                                                   (33, 70, synth.random_u8, 2.0, 0)])
+def test_nis_sharpen_strict_bit_exact(gpu, w, h, gen, radius, debug):
+    img8 = gen(w, h, 31)
+    want = _nis_oracle_sharpen(img8, 0.75, radius, debug=debug)
+    got = run_gpu(img8, w, h, np.float32, precision=STRICT, use_nis=1, render_scale=1.0, sharpness=0.75, radius=radius,
+                  debug_mode=debug)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "max abs diff %g" % np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh,gen", NIS_SHAPES)
+def test_nis_scaler_fp32_tolerance(gpu, iw, ih, ow, oh, gen):
+    # NIS is full of hard thresholds (GetEdgeMap, phase quantisation): the product build (FMA contraction,
+    # v_rcp) may flip one on a near-tie, so the bound is statistical: 99.9 % of values within 1e-3 (north_star's
+    # tolerance), every value within 0.05, UNORM8 outputs 99.9 % within 1 LSB.
+    img8 = gen(iw, ih, 21)
+    want = _nis_oracle_upscale(img8, ow, oh, 0.9)
+    got = run_gpu(img8, ow, oh, np.float32, precision=FP32, use_nis=1, sharpness=0.9)
+    err = np.abs(got - want)
+    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (float((err <= 1e-3).mean()), float(err.max()))
+    got8 = run_gpu(img8, ow, oh, np.uint8, precision=FP32, use_nis=1, sharpness=0.9)
+    d = np.abs(got8.astype(np.int16) - O.float_to_unorm8(want).astype(np.int16))
+    assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
+
+
+def test_nis_rejects_out_of_range_scale(gpu):
+    import openvr_fsr_amd as A
+    with pytest.raises(A.OvrFsrError):
+        run_gpu(synth.random_u8(40, 40, 1), 100, 100, np.uint8, use_nis=1)   # scale 0.4: NVScalerUpdateConfig -> false
