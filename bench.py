@@ -27,10 +27,11 @@ import torch  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable by a float4 copy
 
 WORKLOADS = {
-    # name: (inW, inH, outW, outH, in/out dtype, radius)
-    "C2": (1683, 1869, 2244, 2492, torch.uint8, 2.0),
-    "C4": (2244, 2492, 2916, 3240, torch.uint8, 2.0),
-    "C5": (2370, 2370, 3160, 3160, torch.float16, 0.5),
+    # name: (inW, inH, outW, outH, in/out dtype, radius, use_nis)   -- BASELINE.json configs
+    "C2": (1683, 1869, 2244, 2492, torch.uint8, 2.0, 0),     # EASU+RCAS stereo pairs (headline)
+    "C3": (1683, 1869, 2244, 2492, torch.uint8, 2.0, 1),     # NIS scaler (built-in USM sharpen)
+    "C4": (2244, 2492, 2916, 3240, torch.uint8, 2.0, 0),     # renderScale 1.3 batch
+    "C5": (2370, 2370, 3160, 3160, torch.float16, 0.5, 0),   # radius-masked, RGBA16F packed I/O
 }
 
 
@@ -63,6 +64,31 @@ def synth_batch(n_img, w, h, dtype, device, base_seed):
             out[i, ..., :3] = img.to(dtype)
             out[i, ..., 3] = 1.0
     return out
+
+
+def shard_seed(pairs_per_gpu, rank):
+    """Seed of the first eye image of `rank`'s shard: image g (global index) has seed 0x5EED0000 + g, i.e.
+    0x5EED0000 + 2*pair + eye; rank r owns global pairs [r*P, (r+1)*P)."""
+    return 0x5EED0000 + 2 * pairs_per_gpu * rank
+
+
+def timed_region(step, steps, barrier):
+    """EXACTLY `steps` calls of step() bracketed by barrier()+sync on both sides; returns local wall seconds."""
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(dt, world, device):
+    if world == 1:
+        return dt
+    import torch.distributed as dist
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def time_events(fn, iters, stream):
@@ -116,14 +142,14 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import openvr_fsr_amd as A
-    inW, inH, outW, outH, dtype, radius = WORKLOADS[args.workload]
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
     sharpness = 0.9
     prec = {"fp32": A.PRECISION_FP32, "fp16": A.PRECISION_FP16, "strict": A.PRECISION_FP32_STRICT}[args.precision]
     n_img = 2 * args.pairs
-    base_seed = 0x5EED0000 + 2 * args.pairs * rank
+    base_seed = shard_seed(args.pairs, rank)
     texs = synth_batch(n_img, inW, inH, dtype, dev, base_seed)
     outs = torch.empty((n_img, outH, outW, 4), dtype=dtype, device=dev)
-    pp = A.PostProcessor(fsr_enabled=1, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
+    pp = A.PostProcessor(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
                          precision=prec, fused=args.fused, quantize_intermediate=1, device=local_rank)
 
     def step():
@@ -137,16 +163,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(timed_region(step, args.steps, barrier), world, dev)
 
     pairs_total = args.pairs * world * args.steps
     value = pairs_total / dt
@@ -158,23 +175,23 @@ def main():
     roof = None
     if rank == 0:
         ms_step = time_events(step, max(5, args.steps // 2), stream)
-        # dominant kernel: EASU (two-pass) -- launch it alone over the same batch
-        pe = A.PostProcessor(fsr_enabled=1, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
+        # dominant kernel: EASU of the two-pass pipeline (NVScaler for NIS) -- launch it alone over the same batch
+        pe = A.PostProcessor(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
                              precision=prec, stage_mask=1, device=local_rank)
         ms_easu = time_events(lambda: pe.apply_batch(texs, outs, first_eye=A.EYE_LEFT, alternate_eyes=True),
                               max(5, args.steps // 2), stream)
         pe.close()
         easu_bytes = bpp * (inW * inH + outW * outH) * n_img
         ach = easu_bytes / (ms_easu * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "easu_fast_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": "nis_scaler_kernel" if use_nis else "easu_fast_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
                 "launch_ms": round(ms_easu, 4), "algorithmic_bytes_per_launch": easu_bytes,
                 "pipeline_ms_per_step_events": round(ms_step, 4),
                 "pipeline_achieved_GBps": round(algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9, 1),
-                "note": "EASU is VALU-bound on this chip (see DESIGN.md); frac is reported against the HBM roof the contract names"}
+                "note": "the kernel is VALU-issue-bound on this chip (see DESIGN.md); frac is reported against the HBM roof the contract names"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu and not use_nis and dtype == torch.uint8:
         cpu = cpu_baseline(inW, inH, outW, outH, sharpness)
 
     if rank == 0:
@@ -185,8 +202,9 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "strict": "f32"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, EASU+RCAS, sharpness 0.9, radius %.1f, UNORM8 intermediate"
-                                   % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F", radius),
+            "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, %s, sharpness 0.9, radius %.1f"
+                                   % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F",
+                                      "NIS NVScaler" if use_nis else "EASU+RCAS (UNORM8 intermediate)", radius),
                        "pairs_per_gpu_per_step": args.pairs, "precision": args.precision,
                        "parallelism": "batch sharded over %d GPU(s), no collective" % world},
             "roofline": roof, "cpu_baseline": cpu,

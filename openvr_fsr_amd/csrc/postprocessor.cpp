@@ -87,8 +87,11 @@ int PostProcessor::EnsureBuffer(void **buf, size_t *have, size_t need)
 
 uint32_t PostProcessor::IntermediateFormat() const
 {
-    // the reference's upscaledTexture is R8G8B8A8_UNORM (PostProcessor.cpp:348 via :63-74)
-    return cfg_.quantize_intermediate ? OVRFSR_FORMAT_RGBA8_UNORM : OVRFSR_FORMAT_RGBA32F;
+    // the reference's upscaledTexture has the output format: R8G8B8A8_UNORM (PostProcessor.cpp:348 via :63-74).
+    // Half-float pipelines (BASELINE C5) keep a half-float intermediate; quantize_intermediate=0 keeps fp32.
+    if (!cfg_.quantize_intermediate) return OVRFSR_FORMAT_RGBA32F;
+    return inputFormat_ == OVRFSR_FORMAT_RGBA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM
+         : inputFormat_ == OVRFSR_FORMAT_RGBA16F ? OVRFSR_FORMAT_RGBA16F : OVRFSR_FORMAT_RGBA32F;
 }
 
 void PostProcessor::PrepareUpscalingResources()

@@ -220,3 +220,70 @@ def test_nis_rejects_out_of_range_scale(gpu):
     import openvr_fsr_amd as A
     with pytest.raises(A.OvrFsrError):
         run_gpu(synth.random_u8(40, 40, 1), 100, 100, np.uint8, use_nis=1)   # scale 0.4: NVScalerUpdateConfig -> false
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes
+# ------------------------------------------------------------------------------------------------
+def test_c1_c2_full_size_strict_bit_exact(gpu):
+    """C1 (EASU only, left eye) and C2 (EASU+RCAS) at 1683x1869 -> 2244x2492, bit-exact in the strict build."""
+    iw, ih, ow, oh = 1683, 1869, 2244, 2492
+    img8 = synth.structured_u8(iw, ih, synth.seed_for(0, 0))
+    want_e = O.easu(O.unorm8_to_float(img8), ow, oh)
+    got_e = run_gpu(img8, ow, oh, np.float32, precision=STRICT, stage_mask=1)
+    assert np.array_equal(got_e.view(np.uint32), want_e.view(np.uint32))
+    want8 = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9)
+    got8 = run_gpu(img8, ow, oh, np.uint8, precision=STRICT, sharpness=0.9)
+    assert np.array_equal(got8, want8)
+    # product build at full size: stated tolerances
+    got_f = run_gpu(img8, ow, oh, np.float32, precision=FP32, stage_mask=1)
+    assert np.abs(got_f - want_e).max() <= FLOAT_TOL
+    got8p = run_gpu(img8, ow, oh, np.uint8, precision=FP32, sharpness=0.9)
+    mx, frac = lsb_stats(got8p, want8)
+    assert mx <= RCAS_LSB and frac <= LSB_FRACTION, (mx, frac)
+
+
+def test_c3_full_size_nis(gpu):
+    iw, ih, ow, oh = 1683, 1869, 2244, 2492
+    img8 = synth.structured_u8(iw, ih, synth.seed_for(0, 1))
+    want = _nis_oracle_upscale(img8, ow, oh, 0.9)
+    got = run_gpu(img8, ow, oh, np.float32, eye=1, precision=STRICT, use_nis=1, sharpness=0.9)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    got = run_gpu(img8, ow, oh, np.float32, eye=1, precision=FP32, use_nis=1, sharpness=0.9)
+    err = np.abs(got - want)
+    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (float((err <= 1e-3).mean()), float(err.max()))
+
+
+def test_c4_c5_shapes_properties(gpu):
+    """C4 (2244x2492 -> 2916x3240) and C5 (radius-masked 3160x3160, RGBA16F I/O): size-independent properties."""
+    import torch
+    import openvr_fsr_amd as A
+    # constant image is a fixed point of EASU+RCAS away from the border (border taps of RCAS read 0)
+    for (iw, ih, ow, oh, dt, radius) in [(2244, 2492, 2916, 3240, torch.uint8, 2.0), (2370, 2370, 3160, 3160, torch.float16, 0.5)]:
+        const = torch.empty((ih, iw, 4), dtype=dt, device="cuda")
+        if dt == torch.uint8:
+            const[...] = torch.tensor([64, 128, 191, 255], dtype=dt, device="cuda")
+        else:
+            const[...] = torch.tensor([0.25, 0.5, 0.75, 1.0], dtype=dt, device="cuda")
+        pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.9, radius=radius)
+        out = pp.apply(0, const, out_dtype=dt)
+        torch.cuda.synchronize()
+        inner = out[2:-2, 2:-2].float()
+        ref = const[0, 0].float()
+        tol = 1.0 if dt == torch.uint8 else 2e-3
+        assert (inner - ref).abs().max().item() <= tol
+        assert out.shape == (oh, ow, 4)
+        pp.close()
+    # C5 against the oracle on a half-float image: unit-domain path, masked, RGBA16F in and out
+    iw, ih, ow, oh = 2370, 2370, 3160, 3160
+    img8 = synth.structured_u8(iw, ih, 77)
+    imgh = (img8.astype(np.float32) / 255.0).astype(np.float16)
+    centre, rad = O.mask_constants(ow, oh, 0.5)
+    e = O.easu(imgh.astype(np.float32), ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
+    e16 = e.astype(np.float16).astype(np.float32)                       # half-float intermediate texture
+    want = O.rcas(e16, O.rcas_con(0.9), centre, rad)
+    got = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5)
+    assert np.array_equal(got, want.astype(np.float16))
+    got = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5).astype(np.float32)
+    err = np.abs(got - want.astype(np.float16).astype(np.float32))
+    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 2e-2, (float((err <= 1e-3).mean()), float(err.max()))

@@ -116,10 +116,12 @@ def test_mask_outside_is_bilinear_and_blocky():
                 assert not blk.all()
     assert 0 < inside_groups < 25
     # outside pixel = bilinear sample at pos/outSize (no half-pixel centre): check one by hand
-    x, y = 2, 3
+    x, y = 3, 5
     tx, ty = np.float32(x) / np.float32(ow) * np.float32(iw) - np.float32(0.5), np.float32(y) / np.float32(oh) * np.float32(ih) - np.float32(0.5)
-    x0, y0 = int(np.floor(tx)), int(np.floor(ty))
-    fx, fy = tx - x0, ty - y0
+    # D3D11 texel addressing: 8 fractional bits (D3D11_SUBTEXEL_FRACTIONAL_BIT_COUNT), round to nearest
+    sx, sy = np.floor(tx * 256 + 0.5), np.floor(ty * 256 + 0.5)
+    x0, y0 = int(np.floor(sx / 256)), int(np.floor(sy / 256))
+    fx, fy = np.float32((sx - x0 * 256) / 256), np.float32((sy - y0 * 256) / 256)
     cl = lambda v, hi: min(max(v, 0), hi)
     p = lambda xx, yy: img[cl(yy, ih - 1), cl(xx, iw - 1), :3]
     want = p(x0, y0) * (1 - fx) * (1 - fy) + p(x0 + 1, y0) * fx * (1 - fy) + p(x0, y0 + 1) * (1 - fx) * fy + p(x0 + 1, y0 + 1) * fx * fy
