@@ -287,3 +287,64 @@ def test_c4_c5_shapes_properties(gpu):
     got = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5).astype(np.float32)
     err = np.abs(got - want.astype(np.float16).astype(np.float32))
     assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 2e-2, (float((err <= 1e-3).mean()), float(err.max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# one side-by-side texture holding both eyes (PostProcessor.cpp:146,155-158,298-301)
+# ------------------------------------------------------------------------------------------------
+def test_shared_side_by_side_texture(gpu):
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 240, 100, 320, 133          # both eyes in one 240-wide texture
+    proj = (0.42, 0.55, 0.61, 0.47)
+    img8 = synth.structured_u8(iw, ih, 9)
+    want = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.8, radius=0.7, proj=proj, one_eye_per_texture=False, eye=0, debug=1)
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.8, radius=0.7, proj_centre=proj,
+                         debug_mode=1, precision=STRICT)
+    tex = torch.from_numpy(img8).cuda()
+    left = A.Bounds(0.0, 0.0, 0.5, 1.0)           # |uMax-uMin| <= 0.5 -> texture contains both eyes
+    right = A.Bounds(0.5, 0.0, 1.0, 1.0)
+    out_l = pp.apply(A.EYE_LEFT, tex, bounds=left)
+    torch.cuda.synchronize()
+    got_l = out_l.cpu().numpy().copy()
+    # poison the ctx-owned output: the second Submit of the same texture must NOT re-run the kernels (:155-158)
+    out_l.fill_(7)
+    out_r = pp.apply(A.EYE_RIGHT, tex, bounds=right)
+    torch.cuda.synchronize()
+    assert out_r.data_ptr() == out_l.data_ptr()
+    assert (out_r.cpu().numpy() == 7).all()
+    assert np.array_equal(got_l, want)
+    # next frame (eyeCount wrapped to 0): processed again
+    out_l2 = pp.apply(A.EYE_LEFT, tex, bounds=left)
+    torch.cuda.synchronize()
+    assert np.array_equal(out_l2.cpu().numpy(), want)
+    # a size change rebuilds everything (PostProcessor.cpp:136-143)
+    img2 = synth.structured_u8(120, 100, 10)
+    pp2_want = O.fsr_pipeline_u8(img2, ow, oh, sharpness=0.8, radius=0.7, proj=proj, one_eye_per_texture=True, eye=1, debug=1)
+    out2 = pp.apply(A.EYE_RIGHT, torch.from_numpy(img2).cuda())   # default bounds -> one eye per texture
+    torch.cuda.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), pp2_want)
+    pp.close()
+
+
+def test_disabled_and_reset_behaviour(gpu):
+    import torch
+    import openvr_fsr_amd as A
+    t = torch.from_numpy(synth.random_u8(40, 30, 1)).cuda()
+    pp = A.PostProcessor(fsr_enabled=0)
+    assert pp.apply(0, t).data_ptr() == t.data_ptr()           # fsr disabled: texture forwarded untouched (:135)
+    pp.close()
+    pp = A.PostProcessor(fsr_enabled=1, use_nis=1, out_width=100, out_height=75)   # NIS cannot do 2.5x -> ctx disables itself
+    with pytest.raises(A.OvrFsrError) as e1:
+        pp.apply(0, t, out_dtype=torch.uint8)
+    assert e1.value.status == 2
+    with pytest.raises(A.OvrFsrError) as e2:
+        pp.apply(0, t, out_dtype=torch.uint8)
+    assert e2.value.status == 5                                 # OVRFSR_ERR_DISABLED until reset (:148-151)
+    pp.reset()
+    pp.set_config(A.Config.default(fsr_enabled=1, out_width=53, out_height=40, sharpness=0.9, radius=2.0))
+    out = pp.apply(0, t, out_dtype=torch.uint8)
+    torch.cuda.synchronize()
+    mx, frac = lsb_stats(out.cpu().numpy(), O.fsr_pipeline_u8(t.cpu().numpy(), 53, 40, sharpness=0.9))
+    assert mx <= RCAS_LSB and frac <= 5e-3, (mx, frac)
+    pp.close()
