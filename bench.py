@@ -91,6 +91,18 @@ def max_over_ranks(dt, world, device):
     return float(t.item())
 
 
+def measured_traffic(workload, kernel, n_img):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this workload (tools/profile.sh:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic_per_eye.json")
+    try:
+        per_eye = json.load(open(path))[workload]
+        hit = [v for k, v in per_eye.items() if k.endswith("::" + kernel)]
+        return int(hit[0]["hbm_bytes_per_eye"] * n_img) if hit else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def time_events(fn, iters, stream):
     """Average ms per call of fn() measured with HIP events recorded on `stream`."""
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -183,8 +195,9 @@ def main():
         pe.close()
         easu_bytes = bpp * (inW * inH + outW * outH) * n_img
         ach = easu_bytes / (ms_easu * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "nis_scaler_kernel" if use_nis else "easu_fast_kernel", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+        kname = "nis_scaler_kernel" if use_nis else "easu_fast_kernel"
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, kname, n_img),
                 "launch_ms": round(ms_easu, 4), "algorithmic_bytes_per_launch": easu_bytes,
                 "pipeline_ms_per_step_events": round(ms_step, 4),
                 "pipeline_achieved_GBps": round(algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9, 1),

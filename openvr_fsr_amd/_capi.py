@@ -55,7 +55,8 @@ class Config(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libopenvr_fsr_amd.so")
+    # OVRFSR_LIB: A/B benchmarking of two builds of the same library in one gpurun call (tools/ab.sh)
+    return os.environ.get("OVRFSR_LIB") or os.path.join(_HERE, "libopenvr_fsr_amd.so")
 
 
 def have_library():

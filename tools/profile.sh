@@ -25,6 +25,24 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
 PY
   fi
 done
+# HBM bytes per eye image of each ovrfsr kernel: WRITE_SIZE (KiB, calibrated 1.0 on 4-B/lane stores) +
+# 2 x FETCH_SIZE (KiB; gfx950 rocprofv3 reports half the bytes of a coalesced read -- MI355X_MICROARCH.md, confirmed
+# here: RCAS reads exactly its input).  The PMC passes ran with --pairs 4 -> 8 eye images per launch.
+python - "$OUT" <<'PY'
+import json, re, sys, os
+out = sys.argv[1]
+def parse(fn):
+    d = {}
+    for line in open(os.path.join(out, fn)):
+        m = re.match(r"void (ovrfsr_\w+::\w+)<.*?mean=\s*([\d.]+)", line)
+        if m: d[m.group(1)] = float(m.group(2)) * 1024.0
+    return d
+f, w = parse("pmc_FETCH_SIZE.txt"), parse("pmc_WRITE_SIZE.txt")
+res = {k: {"fetch_bytes_per_eye": 2 * f[k] / 8, "write_bytes_per_eye": w.get(k, 0) / 8,
+           "hbm_bytes_per_eye": (2 * f[k] + w.get(k, 0)) / 8} for k in f}
+json.dump(res, open(os.path.join(out, "traffic_per_eye.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
 ls -la "$OUT"
 cat "$OUT/kernel_stats.csv" | cut -c1-220 | head -12
 cat "$OUT"/pmc_*.txt | cut -c1-200
