@@ -68,6 +68,44 @@ static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t
     default: return hipErrorInvalidValue;                                                                \
     }
 
+// LDS of the fused kernel: EASU planes + 34x34 float4 intermediate
+size_t fused_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
+{
+    size_t e = easu_lds_bytes(prec, in_fmt, cellsW, cellsH);
+    e = (e + 15) & ~(size_t)15;
+    return e + (size_t)(kTileW + 2) * (kTileH + 2) * 16;
+}
+
+template <int I, int M, int O>
+static hipError_t fused_go3(bool strict, const FusedArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    const int pitch = easu_fast_pitch(a.cellsW);
+    if (strict) hipLaunchKernelGGL((ovrfsr_strict::fused_kernel<I, M, O, 0>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 40) hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40>), grid, dim3(kThreads), lds, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+template <int I, int O>
+static hipError_t fused_go(int mid_fmt, bool strict, const FusedArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    switch (mid_fmt) {
+    case FMT_RGBA8: return fused_go3<I, FMT_RGBA8, O>(strict, a, grid, lds, s);
+    case FMT_RGBA16F: return fused_go3<I, FMT_RGBA16F, O>(strict, a, grid, lds, s);
+    default: return fused_go3<I, FMT_RGBA32F, O>(strict, a, grid, lds, s);
+    }
+}
+
+hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a, uint32_t batch, hipStream_t s)
+{
+    if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
+    const bool strict = prec == PREC_FP32_STRICT;
+    if (!strict && easu_fast_pitch(a.cellsW) == 0) return hipErrorInvalidValue;
+    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    const size_t lds = fused_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH);
+    OVRFSR_DISPATCH_FMT(fused_go, mid_fmt, strict, a, grid, lds, s)
+}
+
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s)
 {
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;

@@ -113,6 +113,18 @@ void PostProcessor::PrepareUpscalingResources()
     };
     cellsW_ = extent(outputWidth_, kTileW, sx, cx);
     cellsH_ = extent(outputHeight_, kTileH, sy, cy);
+    // fused kernel: EASU runs on the tile plus a 1-pixel ring, origin at pixel (o0 - 1)
+    auto extentRing = [](uint32_t outN, int tile, float s, float c) {
+        int best = 0;
+        for (uint32_t o0 = 0; o0 < outN; o0 += tile) {
+            uint32_t o1 = o0 + tile < outN ? o0 + tile : outN - 1;
+            int f0 = (int)std::floor(mad2((float)o0 - 1.0f, s, c)), f1 = (int)std::floor(mad2((float)o1, s, c));
+            best = f1 - f0 + 4 > best ? f1 - f0 + 4 : best;
+        }
+        return best;
+    };
+    fusedCellsW_ = extentRing(outputWidth_, kTileW, sx, cx);
+    fusedCellsH_ = extentRing(outputHeight_, kTileH, sy, cy);
 }
 
 void PostProcessor::PrepareSharpeningResources()
@@ -161,6 +173,15 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
         if (lds > 64 * 1024) return Fail(OVRFSR_ERR_UNSUPPORTED, "scale ratio needs more LDS than one tile may use");
     }
     if (doSharpen_ && !cfg_.use_nis) PrepareSharpeningResources();
+    // one launch with the intermediate in LDS only on request: on this chip both stages are VALU-bound and the ring
+    // recompute costs more than the HBM round trip saves, so auto (-1) means two kernels
+    useFused_ = false;
+    if (cfg_.fused == 1 && doUpscale_ && doSharpen_ && !cfg_.use_nis) {
+        const bool pitchOk = cfg_.precision == OVRFSR_PRECISION_FP32_STRICT || fusedCellsW_ <= 40;
+        if (!pitchOk || fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) > 64 * 1024)
+            return Fail(OVRFSR_ERR_UNSUPPORTED, "fused kernel: tile footprint does not fit LDS at this scale");
+        useFused_ = true;
+    }
     if (cfg_.debug_mode && !evStart_) {
         if (hipEventCreate(&evStart_) != hipSuccess || hipEventCreate(&evEnd_) != hipSuccess)
             return Fail(OVRFSR_ERR_HIP, "hipEventCreate failed");
@@ -266,6 +287,25 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
     return OVRFSR_OK;
 }
 
+int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                              const ovrfsr_image &out, size_t outStride, hipStream_t stream)
+{
+    FusedArgs a;
+    a.v = make_view(in, inStride, out, outStride);
+    std::memcpy(&a.sx, &easuCon_[0], 4); std::memcpy(&a.sy, &easuCon_[1], 4);
+    std::memcpy(&a.cx, &easuCon_[2], 4); std::memcpy(&a.cy, &easuCon_[3], 4);
+    std::memcpy(&a.sharp, &rcasCon_[0], 4);
+    a.debug = rcasCon_[3];
+    FillMask(a.m, firstEye, alternate);
+    a.cellsW = fusedCellsW_; a.cellsH = fusedCellsH_;
+    a.tilesX = (out.width + kTileW - 1) / kTileW;
+    a.tilesY = (out.height + kTileH - 1) / kTileH;
+    a.quantize = cfg_.quantize_intermediate ? 1u : 0u;
+    hipError_t e = launch_fused(cfg_.precision, (int)in.format, (int)IntermediateFormat(), (int)out.format, a, n, stream);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("fused EASU+RCAS launch: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
+}
+
 int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                                    const ovrfsr_image &out, size_t outStride, hipStream_t stream)
 {
@@ -297,7 +337,9 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
 {
     if (cfg_.debug_mode && evStart_) (void)hipEventRecord(evStart_, stream);
     int rc = OVRFSR_OK;
-    if (doUpscale_ && doSharpen_) {
+    if (useFused_) {
+        rc = ApplyFused(n, firstEye, alternate, in, inStride, out, outStride, stream);
+    } else if (doUpscale_ && doSharpen_) {
         ovrfsr_image mid;
         mid.width = outputWidth_; mid.height = outputHeight_;
         mid.format = IntermediateFormat();

@@ -60,6 +60,8 @@ private:
     uint32_t radius_[4] = {};
     uint32_t maskMode_[2] = {};
     int cellsW_ = 0, cellsH_ = 0;
+    int fusedCellsW_ = 0, fusedCellsH_ = 0; // footprint of the 34x34 EASU block of the fused kernel
+    bool useFused_ = false;
     // NIS: the 256-byte NISConfig (PostProcessor.cpp:307-310) and the coefficient "textures" (:366-381)
     NisConstants nisConfig_ = {};
     float *nisCoefDev_ = nullptr; // coef_scale[512] | coef_usm[512]
@@ -88,6 +90,8 @@ private:
                          const ovrfsr_image &out, size_t outStride, hipStream_t stream); // :563-638
     int ApplyUpscaling(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                        const ovrfsr_image &out, size_t outStride, hipStream_t stream);   // :385-401
+    int ApplyFused(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                   const ovrfsr_image &out, size_t outStride, hipStream_t stream);
     int ApplySharpening(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                         const ovrfsr_image &out, size_t outStride, hipStream_t stream);  // :483-496
     void FillMask(MaskArgs &m, int firstEye, int alternate) const;

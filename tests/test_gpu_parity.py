@@ -348,3 +348,48 @@ def test_disabled_and_reset_behaviour(gpu):
     mx, frac = lsb_stats(out.cpu().numpy(), O.fsr_pipeline_u8(t.cpu().numpy(), 53, 40, sharpness=0.9))
     assert mx <= RCAS_LSB and frac <= 5e-3, (mx, frac)
     pp.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# fused EASU -> RCAS (intermediate in LDS) == the two-kernel path, bit for bit
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", [STRICT, FP32])
+@pytest.mark.parametrize("iw,ih,ow,oh,gen", SHAPES)
+def test_fused_equals_two_pass(gpu, prec, iw, ih, ow, oh, gen):
+    img8 = gen(iw, ih, 3)
+    for quant, dt in [(1, np.uint8), (0, np.float32)]:
+        two = run_gpu(img8, ow, oh, dt, precision=prec, sharpness=0.9, quantize_intermediate=quant, fused=0)
+        one = run_gpu(img8, ow, oh, dt, precision=prec, sharpness=0.9, quantize_intermediate=quant, fused=1)
+        assert np.array_equal(one.view(np.uint8), two.view(np.uint8)), (quant, np.abs(one.astype(np.float32) - two.astype(np.float32)).max())
+    if prec == STRICT:
+        want8 = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9)
+        assert np.array_equal(run_gpu(img8, ow, oh, np.uint8, precision=STRICT, sharpness=0.9, fused=1), want8)
+
+
+@pytest.mark.parametrize("radius,proj,eye,debug", [(0.5, (0.5, 0.5, 0.5, 0.5), 0, 0), (0.6, (0.42, 0.55, 0.61, 0.47), 1, 1),
+                                                   (0.2, (0.9, 0.1, 0.1, 0.9), 0, 1)])
+def test_fused_masked_strict_bit_exact(gpu, radius, proj, eye, debug):
+    iw, ih, ow, oh = 150, 120, 200, 160
+    img8 = synth.structured_u8(iw, ih, 5)
+    want8 = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.7, radius=radius, proj=proj, eye=eye, debug=debug)
+    got8 = run_gpu(img8, ow, oh, np.uint8, eye=eye, precision=STRICT, sharpness=0.7, radius=radius, proj_centre=proj,
+                   debug_mode=debug, fused=1)
+    assert np.array_equal(got8, want8)
+
+
+def test_fused_half_float_and_full_size(gpu):
+    iw, ih, ow, oh = 237, 237, 316, 316
+    imgh = (synth.structured_u8(iw, ih, 77).astype(np.float32) / 255.0).astype(np.float16)
+    two = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5, fused=0)
+    one = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5, fused=1)
+    assert np.array_equal(one.view(np.uint16), two.view(np.uint16))
+    # product build: the compiler may fold an fp32 multiply into the fp32->fp16 conversion (one rounding instead of
+    # two) differently in the two kernels, so a half-float intermediate can differ by one fp16 ulp on rare ties
+    two = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5, fused=0).astype(np.float32)
+    one = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5, fused=1).astype(np.float32)
+    d = np.abs(one - two)
+    assert d.max() <= 4e-3 and (d > 0).mean() <= 1e-3, (float(d.max()), float((d > 0).mean()))
+    iw, ih, ow, oh = 1683, 1869, 2244, 2492
+    img8 = synth.structured_u8(iw, ih, synth.seed_for(1, 0))
+    assert np.array_equal(run_gpu(img8, ow, oh, np.uint8, precision=STRICT, sharpness=0.9, fused=1),
+                          O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9))
