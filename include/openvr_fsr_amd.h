@@ -183,6 +183,16 @@ OVRFSR_API int ovrfsr_nis_sharpen_config(void *cfg256, float sharpness, uint32_t
 OVRFSR_API const float *ovrfsr_nis_coef_scale(void);
 OVRFSR_API const float *ovrfsr_nis_coef_usm(void);
 
+/* ---- data formats either side of the path --------------------------------- */
+
+/* Config::Load (src/postprocess/Config.h:30-63): parse the text of an openvr_mod.cfg (JSON with // comments,
+ * src/openvr_mod.cfg) into cfg with the reference's defaulting rules.  On a parse error cfg holds the struct
+ * defaults and INVALID_ARGUMENT is returned ("Could not read config file").  Hotkey keys are ignored. */
+OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_config *cfg);
+
+/* Stand-in for the F7 capture (PostProcessor.cpp:640-657): dump a device image as a binary PPM. */
+OVRFSR_API int ovrfsr_save_ppm(const ovrfsr_image *img, const char *path, void *stream);
+
 OVRFSR_API uint32_t ovrfsr_abi_version(void);
 
 #ifdef __cplusplus

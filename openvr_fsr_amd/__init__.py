@@ -10,6 +10,6 @@ from ._capi import (  # noqa: F401
     FORMAT_RGBA8, FORMAT_RGBA16F, FORMAT_RGBA32F,
     PRECISION_FP32, PRECISION_FP16, PRECISION_FP32_STRICT,
     EYE_LEFT, EYE_RIGHT,
-    easu_con, rcas_con, mask_constants, nis_scaler_config, nis_sharpen_config, nis_coefs, output_size,
+    easu_con, rcas_con, mask_constants, nis_scaler_config, nis_sharpen_config, nis_coefs, output_size, config_from_json,
 )
 from .postprocessor import PostProcessor  # noqa: F401

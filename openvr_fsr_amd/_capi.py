@@ -99,6 +99,8 @@ def library():
     L.ovrfsr_nis_sharpen_config.argtypes = [C.c_void_p, C.c_float] + [C.c_uint32] * 2
     L.ovrfsr_nis_coef_scale.restype = f32p
     L.ovrfsr_nis_coef_usm.restype = f32p
+    L.ovrfsr_config_from_json.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Config)]
+    L.ovrfsr_save_ppm.argtypes = [C.POINTER(Image), C.c_char_p, C.c_void_p]
     if L.ovrfsr_abi_version() != 1:
         raise OvrFsrError(1, "ABI version mismatch")
     _LIB = L
@@ -147,6 +149,14 @@ def nis_coefs():
     s = np.ctypeslib.as_array(L.ovrfsr_nis_coef_scale(), shape=(64, 8)).copy()
     u = np.ctypeslib.as_array(L.ovrfsr_nis_coef_usm(), shape=(64, 8)).copy()
     return s, u
+
+
+def config_from_json(text):
+    """Config::Load on the text of an openvr_mod.cfg; returns (status, Config)."""
+    cfg = Config()
+    b = text.encode() if isinstance(text, str) else text
+    rc = library().ovrfsr_config_from_json(b, len(b), C.byref(cfg))
+    return rc, cfg
 
 
 def output_size(cfg, inW, inH):

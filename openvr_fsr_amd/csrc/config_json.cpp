@@ -1,0 +1,155 @@
+// config_json.cpp -- reads the reference's openvr_mod.cfg (JSON with // comments) into ovrfsr_config,
+// with the defaulting rules of Config::Load (src/postprocess/Config.h:30-63): every key is optional,
+// missing "sharpness" means 1.0 (not the struct default 0.75), negative sharpness becomes 0, and a
+// file that cannot be parsed leaves the struct defaults in place ("Could not read config file").
+// Hotkey settings are parsed past and ignored (Win32 virtual-key codes have no meaning here).
+// Also: a binary PPM dump of a device image, standing in for the F7 DDS capture
+// (PostProcessor.cpp:640-657 via ScreenGrab11) as the "image out" format for visual diffs.
+#include <hip/hip_runtime.h>
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/openvr_fsr_amd.h"
+
+namespace {
+
+// Minimal JSON reader: objects, arrays, strings, numbers, true/false/null, // and /* */ comments.
+// Only the scalar leaves of the top-level "fsr" object are kept, addressed as "key" or "sub.key".
+struct Parser {
+    const char *p, *end;
+    bool ok = true;
+    std::map<std::string, std::string> leaves; // path -> literal text ("true", "0.77", ...)
+
+    void ws()
+    {
+        for (;;) {
+            while (p < end && std::isspace((unsigned char)*p)) ++p;
+            if (p + 1 < end && p[0] == '/' && p[1] == '/') { while (p < end && *p != '\n') ++p; continue; }
+            if (p + 1 < end && p[0] == '/' && p[1] == '*') {
+                p += 2;
+                while (p + 1 < end && !(p[0] == '*' && p[1] == '/')) ++p;
+                p = p + 2 <= end ? p + 2 : end;
+                continue;
+            }
+            return;
+        }
+    }
+    bool lit(char c) { ws(); if (p < end && *p == c) { ++p; return true; } return false; }
+    std::string str()
+    {
+        std::string s;
+        ws();
+        if (p >= end || *p != '"') { ok = false; return s; }
+        ++p;
+        while (p < end && *p != '"') {
+            if (*p == '\\' && p + 1 < end) ++p;
+            s.push_back(*p++);
+        }
+        if (p >= end) ok = false; else ++p;
+        return s;
+    }
+    void value(const std::string &path, int depth)
+    {
+        ws();
+        if (p >= end || depth > 16) { ok = false; return; }
+        if (*p == '{') {
+            ++p;
+            if (lit('}')) return;
+            do {
+                std::string k = str();
+                if (!ok || !lit(':')) { ok = false; return; }
+                value(path.empty() ? k : path + "." + k, depth + 1);
+                if (!ok) return;
+            } while (lit(','));
+            if (!lit('}')) ok = false;
+        } else if (*p == '[') {
+            ++p;
+            if (lit(']')) return;
+            int i = 0;
+            do { value(path + "[" + std::to_string(i++) + "]", depth + 1); if (!ok) return; } while (lit(','));
+            if (!lit(']')) ok = false;
+        } else if (*p == '"') {
+            leaves[path] = str();
+        } else {
+            const char *s = p;
+            while (p < end && (std::isalnum((unsigned char)*p) || *p == '+' || *p == '-' || *p == '.')) ++p;
+            if (p == s) { ok = false; return; }
+            leaves[path] = std::string(s, p);
+        }
+    }
+};
+
+bool as_bool(const std::map<std::string, std::string> &m, const char *k, bool def)
+{
+    auto it = m.find(k);
+    if (it == m.end()) return def;
+    if (it->second == "true") return true;
+    if (it->second == "false" || it->second == "null") return false;
+    return std::atof(it->second.c_str()) != 0.0; // jsoncpp asBool(): non-zero numbers are true
+}
+float as_float(const std::map<std::string, std::string> &m, const char *k, double def)
+{
+    auto it = m.find(k);
+    if (it == m.end()) return (float)def;
+    if (it->second == "true") return 1.0f;
+    if (it->second == "false" || it->second == "null") return 0.0f;
+    return (float)std::atof(it->second.c_str()); // asFloat(): double -> float
+}
+
+} // namespace
+
+extern "C" {
+
+OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_config *cfg)
+{
+    if (!cfg || (!text && len)) return OVRFSR_ERR_INVALID_ARGUMENT;
+    ovrfsr_config_default(cfg);
+    Parser ps{text, text + len};
+    ps.value("", 0);
+    ps.ws();
+    if (!ps.ok || ps.p != ps.end) return OVRFSR_ERR_INVALID_ARGUMENT; // struct defaults stay, like the reference's catch(...)
+    const auto &m = ps.leaves;
+    cfg->fsr_enabled = as_bool(m, "fsr.enabled", false);
+    cfg->sharpness = as_float(m, "fsr.sharpness", 1.0);
+    if (cfg->sharpness < 0) cfg->sharpness = 0;
+    cfg->render_scale = as_float(m, "fsr.renderScale", 1.0);
+    cfg->radius = as_float(m, "fsr.radius", 0.5);
+    cfg->debug_mode = as_bool(m, "fsr.debugMode", false);
+    cfg->use_nis = as_bool(m, "fsr.useNIS", false);
+    return OVRFSR_OK;
+}
+
+// Binary PPM (P6) of a device image; RGBA16F/32F are converted like a UNORM8 store.  Synchronises `stream`.
+OVRFSR_API int ovrfsr_save_ppm(const ovrfsr_image *img, const char *path, void *stream)
+{
+    if (!img || !img->data || !path || img->format > OVRFSR_FORMAT_RGBA32F) return OVRFSR_ERR_INVALID_ARGUMENT;
+    const size_t tb = img->format == OVRFSR_FORMAT_RGBA8_UNORM ? 4 : img->format == OVRFSR_FORMAT_RGBA16F ? 8 : 16;
+    std::vector<unsigned char> host((size_t)img->pitch_bytes * img->height);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(host.data(), img->data, host.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return OVRFSR_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return OVRFSR_ERR_HIP;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return OVRFSR_ERR_INVALID_ARGUMENT;
+    std::fprintf(f, "P6\n%u %u\n255\n", img->width, img->height);
+    std::vector<unsigned char> row((size_t)img->width * 3);
+    auto q = [](float x) { x = x < 0 ? 0 : (x > 1 ? 1 : x); return (unsigned char)std::floor(x * 255.0f + 0.5f); };
+    for (uint32_t y = 0; y < img->height; ++y) {
+        const unsigned char *src = host.data() + (size_t)y * img->pitch_bytes;
+        for (uint32_t x = 0; x < img->width; ++x)
+            for (int c = 0; c < 3; ++c) {
+                if (tb == 4) row[x * 3 + c] = src[x * 4 + c];
+                else if (tb == 16) { float v; std::memcpy(&v, src + x * 16 + c * 4, 4); row[x * 3 + c] = q(v); }
+                else { _Float16 h; std::memcpy(&h, src + x * 8 + c * 2, 2); row[x * 3 + c] = q((float)h); }
+            }
+        std::fwrite(row.data(), 1, row.size(), f);
+    }
+    std::fclose(f);
+    return OVRFSR_OK;
+}
+
+} // extern "C"

@@ -393,3 +393,18 @@ def test_fused_half_float_and_full_size(gpu):
     img8 = synth.structured_u8(iw, ih, synth.seed_for(1, 0))
     assert np.array_equal(run_gpu(img8, ow, oh, np.uint8, precision=STRICT, sharpness=0.9, fused=1),
                           O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9))
+
+
+def test_capture_ppm(gpu, tmp_path):
+    import ctypes as C
+    import torch
+    import openvr_fsr_amd as A
+    from openvr_fsr_amd.postprocessor import image_of
+    img8 = synth.structured_u8(37, 21, 4)
+    t = torch.from_numpy(img8).cuda()
+    path = str(tmp_path / "cap.ppm")
+    img = image_of(t)
+    assert A.library().ovrfsr_save_ppm(C.byref(img), path.encode(), None) == 0
+    raw = open(path, "rb").read()
+    header = b"P6\n37 21\n255\n"
+    assert raw.startswith(header) and raw[len(header):] == img8[..., :3].tobytes()
