@@ -80,10 +80,23 @@ template <int I, int M, int O>
 static hipError_t fused_go3(bool strict, const FusedArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
     const int pitch = easu_fast_pitch(a.cellsW);
-    if (strict) hipLaunchKernelGGL((ovrfsr_strict::fused_kernel<I, M, O, 0>), grid, dim3(kThreads), lds, s, a);
-    else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32>), grid, dim3(kThreads), lds, s, a);
-    else if (pitch == 40) hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40>), grid, dim3(kThreads), lds, s, a);
-    else return hipErrorInvalidValue;
+    // the EASU planes plus the 34x34 intermediate can exceed the 64 KiB default cap on dynamic LDS (160 KiB per CU)
+    auto raise = [](const void *fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    if (strict) {
+        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_strict::fused_kernel<I, M, O, 0>));
+        if (once != hipSuccess) return once;
+        hipLaunchKernelGGL((ovrfsr_strict::fused_kernel<I, M, O, 0>), grid, dim3(kThreads), lds, s, a);
+    } else if (pitch == 32) {
+        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 32>));
+        if (once != hipSuccess) return once;
+        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32>), grid, dim3(kThreads), lds, s, a);
+    } else if (pitch == 40) {
+        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 40>));
+        if (once != hipSuccess) return once;
+        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40>), grid, dim3(kThreads), lds, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 template <int I, int O>

@@ -13,6 +13,18 @@ static uint32_t texel_bytes(uint32_t fmt)
     return fmt == OVRFSR_FORMAT_RGBA8_UNORM ? 4u : fmt == OVRFSR_FORMAT_RGBA16F ? 8u : 16u;
 }
 
+// hipSetDevice for the duration of a call, then back to whatever the caller had selected
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int dev)
+    {
+        (void)hipGetDevice(&prev);
+        err = hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // a*b+c with two roundings, identical to the kernels' mad_unfused (separate statements)
 static inline float mad2(float a, float b, float c)
 {
@@ -178,7 +190,7 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
     useFused_ = false;
     if (cfg_.fused == 1 && doUpscale_ && doSharpen_ && !cfg_.use_nis) {
         const bool pitchOk = cfg_.precision == OVRFSR_PRECISION_FP32_STRICT || fusedCellsW_ <= 40;
-        if (!pitchOk || fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) > 64 * 1024)
+        if (!pitchOk || fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) > 160 * 1024)
             return Fail(OVRFSR_ERR_UNSUPPORTED, "fused kernel: tile footprint does not fit LDS at this scale");
         useFused_ = true;
     }
@@ -373,8 +385,8 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
         *out = *in;
         return OVRFSR_OK;
     }
-    hipError_t he = hipSetDevice(device_);
-    if (he != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
+    DeviceGuard guard(device_);
+    if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
 
     if (initialized_ && (in->width != inputWidth_ || in->height != inputHeight_ || in->format != inputFormat_))
         Reset(); // "Texture size changed, recreating resources" (:139-142)
@@ -430,8 +442,8 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     if (!cfg_.fsr_enabled) return Fail(OVRFSR_ERR_DISABLED, "fsr_enabled is 0: nothing to launch");
     if (n > 1 && (inStride < (size_t)in0->pitch_bytes * in0->height || outStride < (size_t)out0->pitch_bytes * out0->height))
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "batch stride smaller than one image");
-    hipError_t he = hipSetDevice(device_);
-    if (he != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(he));
+    DeviceGuard guard(device_);
+    if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
     if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || !textureContainsOnlyOneEye_))
         Reset();
     if (!initialized_) {
