@@ -35,6 +35,19 @@ WORKLOADS = {
 }
 
 
+def random_batch(n_img, w, h, dtype, device, base_seed):
+    """Uniform-random texels (second distribution of SURVEY.md 8d: no smooth regions, worst case for edge analysis)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(base_seed)
+    if dtype == torch.uint8:
+        out = torch.randint(0, 256, (n_img, h, w, 4), generator=g, device=device, dtype=torch.uint8)
+        out[..., 3] = 255
+    else:
+        out = torch.rand((n_img, h, w, 4), generator=g, device=device).to(dtype)
+        out[..., 3] = 1.0
+    return out
+
+
 def synth_batch(n_img, w, h, dtype, device, base_seed):
     """Structured synthetic eye images generated ON the consuming GPU: sinusoid gradients,
     hard 45/135-degree edges, +-4/255 noise, a constant block; alpha = 1."""
@@ -140,6 +153,8 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "strict"])
     ap.add_argument("--fused", type=int, default=-1)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--content", default="structured", choices=["structured", "random"],
+                    help="synthetic eye content: structured (gradients+edges+noise, default) or uniform random")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,7 +174,7 @@ def main():
     prec = {"fp32": A.PRECISION_FP32, "fp16": A.PRECISION_FP16, "strict": A.PRECISION_FP32_STRICT}[args.precision]
     n_img = 2 * args.pairs
     base_seed = shard_seed(args.pairs, rank)
-    texs = synth_batch(n_img, inW, inH, dtype, dev, base_seed)
+    texs = (synth_batch if args.content == "structured" else random_batch)(n_img, inW, inH, dtype, dev, base_seed)
     outs = torch.empty((n_img, outH, outW, 4), dtype=dtype, device=dev)
     pp = A.PostProcessor(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
                          precision=prec, fused=args.fused, quantize_intermediate=1, device=local_rank)
@@ -214,7 +229,7 @@ def main():
             "value": round(value, 2), "unit": "eye-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "strict": "f32"}[args.precision],
-            "data": "synthetic",
+            "data": "synthetic (%s)" % args.content,
             "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, %s, sharpness 0.9, radius %.1f"
                                    % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F",
                                       "NIS NVScaler" if use_nis else "EASU+RCAS (UNORM8 intermediate)", radius),
