@@ -1,0 +1,104 @@
+"""Seeded fuzz of the HIP path against the oracle (strict build: bit-exact): random sizes, scale ratios, masks,
+projection centres, formats, and -- through torch views -- row pitches wider than the image and batch strides with
+gaps.  Catches footprint/tile-extent/addressing corner cases that fixed shapes miss."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+STRICT, FP32 = 2, 0
+
+
+def _cfg(rng):
+    iw, ih = int(rng.integers(5, 150)), int(rng.integers(5, 150))
+    s = float(rng.choice([0.5, 0.59, 0.67, 0.75, 0.77, 0.9, 0.97, rng.uniform(0.5, 1.0)]))
+    ow, oh = max(iw + 1, int(iw / s)), max(ih + 1, int(ih / s))
+    radius = float(rng.choice([2.0, 2.0, rng.uniform(0.15, 1.3)]))
+    proj = tuple(float(x) for x in rng.uniform(0.25, 0.75, 4))
+    return iw, ih, ow, oh, radius, proj, int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(0, 1))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fsr_fuzz_strict(gpu, seed):
+    import torch
+    import openvr_fsr_amd as A
+    rng = np.random.default_rng(1000 + seed)
+    iw, ih, ow, oh, radius, proj, eye, debug, sharp = _cfg(rng)
+    gen = [synth.structured_u8, synth.random_u8, synth.extremes_u8][seed % 3]
+    img8 = gen(iw, ih, seed)
+    want = O.fsr_pipeline_u8(img8, ow, oh, sharpness=sharp, radius=radius, proj=proj, eye=eye, debug=debug)
+    # input lives inside a wider buffer (row pitch > width*4), output likewise
+    pad_in, pad_out = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+    big_in = torch.zeros((ih, iw + pad_in, 4), dtype=torch.uint8, device="cuda")
+    big_in[:, :iw] = torch.from_numpy(img8).cuda()
+    big_out = torch.full((oh, ow + pad_out, 4), 99, dtype=torch.uint8, device="cuda")
+    for fused in (0, 1):
+        pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=sharp, radius=radius, proj_centre=proj,
+                             debug_mode=debug, precision=STRICT, fused=fused)
+        big_out.fill_(99)
+        out = pp.apply(eye, big_in[:, :iw], out=big_out[:, :ow])
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got, want), (fused, iw, ih, ow, oh, radius)
+        if pad_out:
+            assert (big_out[:, ow:].cpu().numpy() == 99).all(), "wrote outside the output image"
+        pp.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_nis_fuzz_strict(gpu, seed):
+    import torch
+    import openvr_fsr_amd as A
+    rng = np.random.default_rng(2000 + seed)
+    iw, ih, ow, oh, radius, proj, eye, debug, sharp = _cfg(rng)
+    ow, oh = min(ow, 2 * iw), min(oh, 2 * ih)     # NIS: 1x..2x
+    gen = [synth.structured_u8, synth.random_u8, synth.extremes_u8][seed % 3]
+    img8 = gen(iw, ih, seed)
+    cs, cu = A.nis_coefs()
+    ok, cfg = A.nis_scaler_config(sharp, iw, ih, ow, oh)
+    assert ok
+    centre, rad = O.mask_constants(ow, oh, radius, proj, True, eye)
+    want = O.nis_upscale(O.unorm8_to_float(img8), ow, oh, O.nis_block(cfg, centre, rad, debug), cs, cu)
+    pad_in = int(rng.integers(0, 9))
+    big_in = torch.zeros((ih, iw + pad_in, 4), dtype=torch.uint8, device="cuda")
+    big_in[:, :iw] = torch.from_numpy(img8).cuda()
+    pp = A.PostProcessor(fsr_enabled=1, use_nis=1, out_width=ow, out_height=oh, sharpness=sharp, radius=radius,
+                         proj_centre=proj, debug_mode=debug, precision=STRICT)
+    out = pp.apply(eye, big_in[:, :iw], out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32)), (iw, ih, ow, oh, radius)
+    pp.close()
+
+
+def test_batch_with_stride_gaps_and_formats(gpu):
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 70, 52, 93, 69
+    n = 5
+    proj = (0.45, 0.5, 0.55, 0.5)
+    imgs8 = np.stack([synth.structured_u8(iw, ih, 40 + i) for i in range(n)])
+    # images spaced 3 rows apart inside one allocation (stride > pitch*height), output too
+    buf_in = torch.zeros((n, ih + 3, iw + 2, 4), dtype=torch.uint8, device="cuda")
+    buf_in[:, :ih, :iw] = torch.from_numpy(imgs8).cuda()
+    buf_out = torch.full((n, oh + 2, ow + 5, 4), 7, dtype=torch.uint8, device="cuda")
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.9, radius=0.8, proj_centre=proj, precision=STRICT)
+    pp.apply_batch(buf_in[:, :ih, :iw], buf_out[:, :oh, :ow], first_eye=1, alternate_eyes=True)
+    torch.cuda.synchronize()
+    got = buf_out.cpu().numpy()
+    for i in range(n):
+        want = O.fsr_pipeline_u8(imgs8[i], ow, oh, sharpness=0.9, radius=0.8, proj=proj, eye=1 ^ (i & 1))
+        assert np.array_equal(got[i, :oh, :ow], want), i
+    assert (got[:, oh:] == 7).all() and (got[:, :, ow:] == 7).all()
+    pp.close()
+    # float formats in and out: RGBA32F -> RGBA16F, strict, against the oracle on the same floats
+    imgf = O.unorm8_to_float(imgs8[0])
+    centre, rad = O.mask_constants(ow, oh, 2.0)
+    e = O.easu(imgf, ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
+    want = O.rcas(e, O.rcas_con(0.5), centre, rad).astype(np.float16)
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.5, radius=2.0, precision=STRICT, quantize_intermediate=0)
+    out = pp.apply(0, torch.from_numpy(imgf).cuda(), out_dtype=torch.float16)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    pp.close()
