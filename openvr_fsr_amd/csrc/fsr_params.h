@@ -58,7 +58,7 @@ struct FusedArgs {
     MaskArgs m;
     int32_t cellsW, cellsH;
     uint32_t tilesX, tilesY;
-    uint32_t quantize;      // 1: EASU result rounded to UNORM8 before RCAS (reference-faithful)
+    uint32_t quantize;      // informational: the intermediate format is a template parameter of fused_kernel
 };
 
 struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) minus the unused viewport fields
