@@ -50,7 +50,7 @@ template <int I, int O>
 static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t s)
 {
     if (strict) hipLaunchKernelGGL((ovrfsr_strict::rcas_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((ovrfsr_fast::rcas_fast_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((ovrfsr_fast::rcas_direct_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

@@ -364,7 +364,16 @@ def test_fused_equals_two_pass(gpu, prec, iw, ih, ow, oh, gen):
     for quant, dt in [(1, np.uint8), (0, np.float32)]:
         two = run_gpu(img8, ow, oh, dt, precision=prec, sharpness=0.9, quantize_intermediate=quant, fused=0)
         one = run_gpu(img8, ow, oh, dt, precision=prec, sharpness=0.9, quantize_intermediate=quant, fused=1)
-        assert np.array_equal(one.view(np.uint8), two.view(np.uint8)), (quant, np.abs(one.astype(np.float32) - two.astype(np.float32)).max())
+        if prec == STRICT:
+            assert np.array_equal(one.view(np.uint8), two.view(np.uint8)), quant
+        else:
+            # product build: the two paths run differently scheduled (differently contracted) RCAS code; the EASU
+            # stage and the intermediate rounding are the same, so they agree to fp32 rounding noise
+            d = np.abs(one.astype(np.float32) - two.astype(np.float32))
+            if dt == np.uint8:
+                assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (quant, float(d.max()), float((d > 0).mean()))
+            else:
+                assert d.max() <= 2e-6, (quant, float(d.max()))
     if prec == STRICT:
         want8 = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9)
         assert np.array_equal(run_gpu(img8, ow, oh, np.uint8, precision=STRICT, sharpness=0.9, fused=1), want8)
