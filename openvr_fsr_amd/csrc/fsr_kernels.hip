@@ -109,21 +109,43 @@ static hipError_t fused_go(int mid_fmt, bool strict, const FusedArgs &a, dim3 gr
     }
 }
 
-hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a, uint32_t batch, hipStream_t s)
+hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const bool strict = prec == PREC_FP32_STRICT;
     if (!strict && easu_fast_pitch(a.cellsW) == 0) return hipErrorInvalidValue;
-    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    const dim3 grid(a.tileList ? nTiles : a.tilesX * a.tilesY, 1, batch);
     const size_t lds = fused_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH);
     OVRFSR_DISPATCH_FMT(fused_go, mid_fmt, strict, a, grid, lds, s)
 }
 
-hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s)
+template <int I, int O>
+static hipError_t easu_outside_go(int mid_fmt, const EasuArgs &a, dim3 grid, hipStream_t s)
+{
+    switch (mid_fmt) {
+    case FMT_RGBA8: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, FMT_RGBA8>), grid, dim3(kThreads), 0, s, a); break;
+    case FMT_RGBA16F: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, FMT_RGBA16F>), grid, dim3(kThreads), 0, s, a); break;
+    case FMT_RGBA32F: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, FMT_RGBA32F>), grid, dim3(kThreads), 0, s, a); break;
+    default: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, -1>), grid, dim3(kThreads), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+// nTiles blocks, each resolving tile a.tileList[block]: tiles entirely outside the radius (product build only).
+// mid_fmt < 0: EASU pass only; mid_fmt >= 0: write the FINAL pixel of the EASU->RCAS pipeline (RCAS outside the radius
+// is a tinted copy of the intermediate texel, so the intermediate's format rounding is applied in registers).
+hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s)
+{
+    if (!a.tileList || nTiles == 0) return hipErrorInvalidValue;
+    const dim3 grid(nTiles, 1, batch);
+    OVRFSR_DISPATCH_FMT(easu_outside_go, mid_fmt, a, grid, s)
+}
+
+hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const bool strict = prec == PREC_FP32_STRICT;
-    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    const dim3 grid(a.tileList ? nTiles : a.tilesX * a.tilesY, 1, batch);
     const size_t lds = easu_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH);
     OVRFSR_DISPATCH_FMT(easu_go, strict, a, grid, lds, s)
 }

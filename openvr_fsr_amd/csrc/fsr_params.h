@@ -26,6 +26,10 @@ struct BatchView {          // image i of a batch lives at base + i*stride
     int32_t inW, inH, outW, outH;
 };
 
+// Bilinear fallback mapping of one output column / row (fsr_easu.hlsl:33-36 with D3D11 8-bit sub-texel
+// addressing), built on the host with the same IEEE operations the kernels and the oracle use.
+struct BilinTap { int32_t i0; float frac; };
+
 struct MaskArgs {           // imageCentre / radius of the reference's cbuffers, one set per eye
     uint32_t centre[2][4];  // [eye][c1x, c1y, c2x, c2y]
     uint32_t r2;            // radius[1]
@@ -40,6 +44,10 @@ struct EasuArgs {
     MaskArgs m;
     int32_t cellsW, cellsH; // LDS input tile extent (max over tiles) incl. the 1+2 apron
     uint32_t tilesX, tilesY;
+    const BilinTap *bilX;   // [outW], [outH] device tables for the bilinear fallback (product build)
+    const BilinTap *bilY;
+    const uint32_t *tileList; // optional: tile index of each block (mask-sorted launch); null = all tiles in XCD order
+    uint32_t debug;           // RCAS const0[3]; only read by the "final" outside kernel (tinted copy of the fused path)
 };
 
 struct RcasArgs {
@@ -59,6 +67,7 @@ struct FusedArgs {
     int32_t cellsW, cellsH;
     uint32_t tilesX, tilesY;
     uint32_t quantize;      // informational: the intermediate format is a template parameter of fused_kernel
+    const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs)
 };
 
 struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) minus the unused viewport fields

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 #include "fsr_launch.h"
 
 namespace ovrfsr {
@@ -54,7 +55,12 @@ void PostProcessor::Reset()
     if (upscaled_) (void)hipFree(upscaled_);
     if (sharpened_) (void)hipFree(sharpened_);
     if (nisCoefDev_) (void)hipFree(nisCoefDev_);
+    if (bilinDev_) (void)hipFree(bilinDev_);
+    if (tileListDev_) (void)hipFree(tileListDev_);
+    tileListDev_ = nullptr;
+    nInside_[0] = nInside_[1] = nOutside_[0] = nOutside_[1] = 0;
     nisCoefDev_ = nullptr;
+    bilinDev_ = nullptr;
     upscaled_ = sharpened_ = nullptr;
     upscaledBytes_ = sharpenedBytes_ = 0;
     lastSubmittedTexture_ = nullptr;
@@ -184,11 +190,41 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
         const size_t lds = easu_lds_bytes(cfg_.precision, (int)in.format, cellsW_, cellsH_);
         if (lds > 64 * 1024) return Fail(OVRFSR_ERR_UNSUPPORTED, "scale ratio needs more LDS than one tile may use");
     }
+    if (doUpscale_ && !cfg_.use_nis) {
+        // column / row taps of the bilinear fallback (SampleLevel at pos/outSize, 8-bit sub-texel snap): same IEEE
+        // operations as fsr_device.inc's bilinear_uv / fixed8, evaluated once per column and row instead of per pixel
+        std::vector<BilinTap> taps((size_t)ow + oh);
+        auto fill = [](BilinTap *t, uint32_t outN, uint32_t inN) {
+            for (uint32_t o = 0; o < outN; ++o) {
+                volatile float u = (float)o / (float)outN;
+                const float tt = mad2(u, (float)inN, -0.5f);
+                const float s = std::floor(mad2(tt, 256.0f, 0.5f));
+                volatile float q = s * (1.0f / 256.0f);
+                const float f = std::floor(q);
+                t[o].i0 = (int32_t)f;
+                t[o].frac = mad2(f, -256.0f, s) * (1.0f / 256.0f);
+            }
+        };
+        fill(taps.data(), ow, in.width);
+        fill(taps.data() + ow, oh, in.height);
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&bilinDev_), taps.size() * sizeof(BilinTap));
+        if (e == hipSuccess) e = hipMemcpy(bilinDev_, taps.data(), taps.size() * sizeof(BilinTap), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("bilinear tap tables: ") + hipGetErrorString(e));
+    }
+    if (doUpscale_ && !cfg_.use_nis && cfg_.precision == OVRFSR_PRECISION_FP32 &&
+        (maskMode_[0] == MASK_MIXED || maskMode_[1] == MASK_MIXED)) {
+        int rc = PrepareTileLists();
+        if (rc != OVRFSR_OK) return rc;
+    }
     if (doSharpen_ && !cfg_.use_nis) PrepareSharpeningResources();
     // one launch with the intermediate in LDS only on request: on this chip both stages are VALU-bound and the ring
     // recompute costs more than the HBM round trip saves, so auto (-1) means two kernels
     useFused_ = false;
-    if (cfg_.fused == 1 && doUpscale_ && doSharpen_ && !cfg_.use_nis) {
+    // auto: masked product-build pipelines run fused + mask-sorted (they are HBM-write-bound, and tiles outside the
+    // radius need no intermediate at all); unmasked ones stay two-pass (VALU-bound, the ring recompute costs 9 %)
+    const bool autoFused = cfg_.fused == -1 && tileListDev_ != nullptr && fusedCellsW_ <= 40 &&
+                           fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) <= 160 * 1024;
+    if ((cfg_.fused == 1 || autoFused) && doUpscale_ && doSharpen_ && !cfg_.use_nis) {
         const bool pitchOk = cfg_.precision == OVRFSR_PRECISION_FP32_STRICT || fusedCellsW_ <= 40;
         if (!pitchOk || fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) > 160 * 1024)
             return Fail(OVRFSR_ERR_UNSUPPORTED, "fused kernel: tile footprint does not fit LDS at this scale");
@@ -199,6 +235,47 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
             return Fail(OVRFSR_ERR_HIP, "hipEventCreate failed");
     }
     initialized_ = true;
+    return OVRFSR_OK;
+}
+
+// The radius mask is static per eye, so the tiles are sorted once on the host: tiles with at least one 16x16 group
+// inside the radius (EASU kernel, LDS-staged) and tiles entirely outside (bilinear only, LDS-free kernel).
+int PostProcessor::PrepareTileLists()
+{
+    const uint32_t tx = (outputWidth_ + kTileW - 1) / kTileW, ty = (outputHeight_ + kTileH - 1) / kTileH;
+    std::vector<uint32_t> lists;
+    std::vector<uint32_t> in[2], outl[2];
+    for (int eye = 0; eye < 2; ++eye) {
+        for (uint32_t t = 0; t < tx * ty; ++t) {
+            const uint32_t tyi = t / tx, txi = t - tyi * tx;
+            bool any = false;
+            for (uint32_t g = 0; g < 4 && !any; ++g) {
+                const uint32_t gx = 2 * txi + (g & 1u), gy = 2 * tyi + (g >> 1);
+                const uint32_t cx = (gx << 4) + 8u, cy = (gy << 4) + 8u;
+                const uint32_t ax = centre_[eye][0] - cx, ay = centre_[eye][1] - cy, bx = centre_[eye][2] - cx, by = centre_[eye][3] - cy;
+                any = (ax * ax + ay * ay <= radius_[1]) || (bx * bx + by * by <= radius_[1]);
+            }
+            (any ? in[eye] : outl[eye]).push_back(t);
+        }
+    }
+    listsShared_ = in[0] == in[1];
+    // block b of a launch goes to XCD b % 8: hand every XCD a contiguous run of the (row-major) list
+    auto xcd_order = [](std::vector<uint32_t> &v) {
+        const uint32_t n = (uint32_t)v.size(), full = n & ~7u;
+        std::vector<uint32_t> r(n);
+        for (uint32_t b = 0; b < n; ++b) r[b] = v[b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b];
+        v.swap(r);
+    };
+    for (int eye = 0; eye < 2; ++eye) {
+        xcd_order(in[eye]); xcd_order(outl[eye]);
+        nInside_[eye] = (uint32_t)in[eye].size(); nOutside_[eye] = (uint32_t)outl[eye].size();
+        listOffInside_[eye] = lists.size(); lists.insert(lists.end(), in[eye].begin(), in[eye].end());
+        listOffOutside_[eye] = lists.size(); lists.insert(lists.end(), outl[eye].begin(), outl[eye].end());
+    }
+    if (lists.empty()) return OVRFSR_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&tileListDev_), lists.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemcpy(tileListDev_, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("tile lists: ") + hipGetErrorString(e));
     return OVRFSR_OK;
 }
 
@@ -287,16 +364,59 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
         return OVRFSR_OK;
     }
     EasuArgs a;
+    FillEasu(a, in, inStride, out, outStride, firstEye, alternate);
+    hipError_t e = hipSuccess;
+    if (!tileListDev_) {
+        e = launch_easu(cfg_.precision, (int)in.format, (int)out.format, a, n, stream);
+    } else {
+        EyePass passes[2];
+        const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
+        for (int p = 0; p < np && e == hipSuccess; ++p) {
+            EasuArgs b = a;
+            const EyePass &ps = passes[p];
+            b.v.in += ps.inOff; b.v.out += ps.outOff; b.v.in_stride = ps.inStride; b.v.out_stride = ps.outStride;
+            if (ps.split) { b.m.first_eye = (uint32_t)ps.eye; b.m.alternate = 0; }
+            if (nInside_[ps.eye]) {
+                b.tileList = tileListDev_ + listOffInside_[ps.eye];
+                e = launch_easu(cfg_.precision, (int)in.format, (int)out.format, b, ps.cnt, stream, nInside_[ps.eye]);
+            }
+            if (e == hipSuccess && nOutside_[ps.eye]) {
+                b.tileList = tileListDev_ + listOffOutside_[ps.eye];
+                e = launch_easu_outside((int)in.format, -1, (int)out.format, b, nOutside_[ps.eye], ps.cnt, stream);
+            }
+        }
+    }
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("EASU launch: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
+}
+
+void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStride, const ovrfsr_image &out, size_t outStride,
+                             int firstEye, int alternate) const
+{
     a.v = make_view(in, inStride, out, outStride);
     std::memcpy(&a.sx, &easuCon_[0], 4); std::memcpy(&a.sy, &easuCon_[1], 4);
     std::memcpy(&a.cx, &easuCon_[2], 4); std::memcpy(&a.cy, &easuCon_[3], 4);
     FillMask(a.m, firstEye, alternate);
     a.cellsW = cellsW_; a.cellsH = cellsH_;
-    a.tilesX = (out.width + kTileW - 1) / kTileW;   // the reference dispatches 16x16 groups (:399);
+    a.bilX = bilinDev_; a.bilY = bilinDev_ + outputWidth_;
+    a.tileList = nullptr;
+    a.debug = rcasCon_[3];
+    a.tilesX = (out.width + kTileW - 1) / kTileW;   // the reference dispatches 16x16 groups (PostProcessor.cpp:399);
     a.tilesY = (out.height + kTileH - 1) / kTileH;  // a tile here is 2x2 of those
-    hipError_t e = launch_easu(cfg_.precision, (int)in.format, (int)out.format, a, n, stream);
-    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("EASU launch: ") + hipGetErrorString(e));
-    return OVRFSR_OK;
+}
+
+// Mask-sorted launches use per-eye tile lists.  Both eyes share the lists when their mask centres coincide;
+// otherwise the images of each eye form their own stride-2 sub-batch (images p, p+2, ... have the same eye).
+int PostProcessor::EyePasses(uint32_t n, int firstEye, int alternate, size_t inStride, size_t outStride, EyePass out[2]) const
+{
+    const bool twoEyes = alternate && n > 1 && !listsShared_;
+    if (!twoEyes) {
+        out[0] = EyePass{firstEye & 1, n, 0, 0, inStride, outStride, false};
+        return 1;
+    }
+    for (int p = 0; p < 2; ++p)
+        out[p] = EyePass{(firstEye & 1) ^ p, (n - p + 1) / 2, (size_t)p * inStride, (size_t)p * outStride, 2 * inStride, 2 * outStride, true};
+    return 2;
 }
 
 int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
@@ -313,7 +433,34 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
     a.tilesX = (out.width + kTileW - 1) / kTileW;
     a.tilesY = (out.height + kTileH - 1) / kTileH;
     a.quantize = cfg_.quantize_intermediate ? 1u : 0u;
-    hipError_t e = launch_fused(cfg_.precision, (int)in.format, (int)IntermediateFormat(), (int)out.format, a, n, stream);
+    a.tileList = nullptr;
+    hipError_t e = hipSuccess;
+    if (!tileListDev_) {
+        e = launch_fused(cfg_.precision, (int)in.format, (int)IntermediateFormat(), (int)out.format, a, n, stream);
+    } else {
+        // masked: tiles entirely outside the radius never need an intermediate (RCAS there is a tinted copy), they are
+        // written in final form by the LDS-free bilinear kernel; only tiles touching the radius run the fused kernel
+        EasuArgs ea;
+        FillEasu(ea, in, inStride, out, outStride, firstEye, alternate);
+        EyePass passes[2];
+        const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
+        for (int p = 0; p < np && e == hipSuccess; ++p) {
+            const EyePass &ps = passes[p];
+            FusedArgs fb = a;
+            EasuArgs eb = ea;
+            fb.v.in += ps.inOff; fb.v.out += ps.outOff; fb.v.in_stride = ps.inStride; fb.v.out_stride = ps.outStride;
+            eb.v = fb.v;
+            if (ps.split) { fb.m.first_eye = eb.m.first_eye = (uint32_t)ps.eye; fb.m.alternate = eb.m.alternate = 0; }
+            if (nInside_[ps.eye]) {
+                fb.tileList = tileListDev_ + listOffInside_[ps.eye];
+                e = launch_fused(cfg_.precision, (int)in.format, (int)IntermediateFormat(), (int)out.format, fb, ps.cnt, stream, nInside_[ps.eye]);
+            }
+            if (e == hipSuccess && nOutside_[ps.eye]) {
+                eb.tileList = tileListDev_ + listOffOutside_[ps.eye];
+                e = launch_easu_outside((int)in.format, (int)IntermediateFormat(), (int)out.format, eb, nOutside_[ps.eye], ps.cnt, stream);
+            }
+        }
+    }
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("fused EASU+RCAS launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;
 }

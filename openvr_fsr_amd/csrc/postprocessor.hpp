@@ -65,6 +65,13 @@ private:
     // NIS: the 256-byte NISConfig (PostProcessor.cpp:307-310) and the coefficient "textures" (:366-381)
     NisConstants nisConfig_ = {};
     float *nisCoefDev_ = nullptr; // coef_scale[512] | coef_usm[512]
+    BilinTap *bilinDev_ = nullptr; // [outW] column taps followed by [outH] row taps of the bilinear fallback
+    // mask-sorted EASU tile lists (product build, masked configs): per eye, tiles with any group inside the radius
+    // and tiles entirely outside; the latter run through an LDS-free kernel at twice the occupancy
+    uint32_t *tileListDev_ = nullptr;
+    uint32_t nInside_[2] = {0, 0}, nOutside_[2] = {0, 0};
+    size_t listOffInside_[2] = {0, 0}, listOffOutside_[2] = {0, 0};
+    bool listsShared_ = false; // both eyes have identical lists
     int nisCellsW_ = 0, nisCellsH_ = 0;
 
     // ctx-owned device buffers: upscaledTexture / sharpenedTexture, PostProcessor.h:43-45,58-59
@@ -82,6 +89,10 @@ private:
     int PrepareResources(const ovrfsr_image &in);                         // :498-561
     void PrepareUpscalingResources();                                    // :285-383
     void PrepareSharpeningResources();                                   // :409-481
+    int PrepareTileLists();
+    struct EyePass { int eye; uint32_t cnt; size_t inOff, outOff, inStride, outStride; bool split; };
+    int EyePasses(uint32_t n, int firstEye, int alternate, size_t inStride, size_t outStride, EyePass out[2]) const;
+    void FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStride, const ovrfsr_image &out, size_t outStride, int firstEye, int alternate) const;
     int PrepareNisResources();                                           // :307-310, :366-382, :432-435
     void FillNis(NisArgs &a, int firstEye, int alternate) const;
     int EnsureBuffer(void **buf, size_t *have, size_t need);

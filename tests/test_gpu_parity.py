@@ -421,3 +421,35 @@ def test_capture_ppm(gpu, tmp_path):
     raw = open(path, "rb").read()
     header = b"P6\n37 21\n255\n"
     assert raw.startswith(header) and raw[len(header):] == img8[..., :3].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+# masked product-build pipeline: mask-sorted tile lists, LDS-free final-output kernel for tiles outside the radius
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("radius,proj,debug", [(0.5, (0.5, 0.5, 0.5, 0.5), 0), (0.6, (0.42, 0.55, 0.61, 0.47), 1), (0.25, (0.8, 0.2, 0.3, 0.7), 1)])
+@pytest.mark.parametrize("fused", [-1, 0, 1])
+def test_masked_product_paths_agree(gpu, radius, proj, debug, fused):
+    """auto (fused + mask-sorted), two-pass mask-sorted and fused mask-sorted all within tolerance of the oracle,
+    including a batch whose two eyes have different mask centres (separate per-eye launches)."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 330, 250, 440, 333
+    imgs = np.stack([synth.structured_u8(iw, ih, 60 + i) for i in range(4)])
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.8, radius=radius, proj_centre=proj,
+                         debug_mode=debug, precision=FP32, fused=fused)
+    outs = torch.empty((4, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    pp.apply_batch(torch.from_numpy(imgs).cuda(), outs, first_eye=1, alternate_eyes=True)
+    torch.cuda.synchronize()
+    got = outs.cpu().numpy()
+    pp.close()
+    for i in range(4):
+        want = O.fsr_pipeline_u8(imgs[i], ow, oh, sharpness=0.8, radius=radius, proj=proj, eye=1 ^ (i & 1), debug=debug)
+        mx, frac = lsb_stats(got[i], want)
+        # outside the radius the pixel is a bilinear blend with 8-bit weights of byte texels: results land exactly on
+        # UNORM8 rounding ties far more often than EASU's, and the product build's contracted FMAs break such ties
+        # differently from the as-written evaluation -> allow 0.5 % of values to differ (still <= 5 LSB, typically 1)
+        assert mx <= RCAS_LSB and frac <= 5e-3, (i, mx, frac)
+    # single image through apply() as well
+    one = run_gpu(imgs[0], ow, oh, np.uint8, eye=1, precision=FP32, sharpness=0.8, radius=radius, proj_centre=proj,
+                  debug_mode=debug, fused=fused)
+    assert np.array_equal(one, got[0])
