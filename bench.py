@@ -202,15 +202,23 @@ def main():
     roof = None
     if rank == 0:
         ms_step = time_events(step, max(5, args.steps // 2), stream)
-        # dominant kernel: EASU of the two-pass pipeline (NVScaler for NIS) -- launch it alone over the same batch
-        pe = A.PostProcessor(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
-                             precision=prec, stage_mask=1, device=local_rank)
-        ms_easu = time_events(lambda: pe.apply_batch(texs, outs, first_eye=A.EYE_LEFT, alternate_eyes=True),
-                              max(5, args.steps // 2), stream)
-        pe.close()
-        easu_bytes = bpp * (inW * inH + outW * outH) * n_img
+        masked_fsr = (radius < 2.0) and not use_nis
+        if masked_fsr:
+            # masked EASU+RCAS runs as ONE fused pipeline (fused_kernel on tiles touching the radius + easu_outside_kernel
+            # writing the rest in final form): the step itself is the dominant "kernel"
+            ms_easu = ms_step
+            easu_bytes = algo_bytes_eye * n_img
+        else:
+            # dominant kernel: EASU of the two-pass pipeline (NVScaler for NIS) -- launch it alone over the same batch
+            cfge = A.Config.default(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=sharpness,
+                                    radius=radius, precision=prec, stage_mask=1)
+            pe = A.PostProcessor(cfg=cfge, device=local_rank)
+            ms_easu = time_events(lambda: pe.apply_batch(texs, outs, first_eye=A.EYE_LEFT, alternate_eyes=True),
+                                  max(5, args.steps // 2), stream)
+            pe.close()
+            easu_bytes = bpp * (inW * inH + outW * outH) * n_img
         ach = easu_bytes / (ms_easu * 1e-3) / 1e9
-        kname = "nis_scaler_kernel" if use_nis else "easu_fast_kernel"
+        kname = "nis_scaler_kernel" if use_nis else ("fused_kernel+easu_outside_kernel" if masked_fsr else "easu_fast_kernel")
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, kname, n_img),
                 "launch_ms": round(ms_easu, 4), "algorithmic_bytes_per_launch": easu_bytes,

@@ -35,9 +35,34 @@ static inline float mad2(float a, float b, float c)
 
 PostProcessor::PostProcessor(int device, const ovrfsr_config &cfg) : device_(device), cfg_(cfg) {}
 
+hipStream_t PostProcessor::Fork(hipStream_t user)
+{
+    if (!auxStream_) {
+        if (hipStreamCreateWithFlags(&auxStream_, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&evFork_, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&evJoin_, hipEventDisableTiming) != hipSuccess) {
+            auxStream_ = nullptr;
+            return user; // no second stream: run everything in order on the caller's stream
+        }
+    }
+    (void)hipEventRecord(evFork_, user);
+    (void)hipStreamWaitEvent(auxStream_, evFork_, 0);
+    return auxStream_;
+}
+
+void PostProcessor::Join(hipStream_t user)
+{
+    if (!auxStream_) return;
+    (void)hipEventRecord(evJoin_, auxStream_);
+    (void)hipStreamWaitEvent(user, evJoin_, 0);
+}
+
 PostProcessor::~PostProcessor()
 {
     Reset();
+    if (auxStream_) (void)hipStreamDestroy(auxStream_);
+    if (evFork_) (void)hipEventDestroy(evFork_);
+    if (evJoin_) (void)hipEventDestroy(evJoin_);
     if (evStart_) (void)hipEventDestroy(evStart_);
     if (evEnd_) (void)hipEventDestroy(evEnd_);
 }
@@ -371,6 +396,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
     } else {
         EyePass passes[2];
         const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
+        hipStream_t aux = Fork(stream);
         for (int p = 0; p < np && e == hipSuccess; ++p) {
             EasuArgs b = a;
             const EyePass &ps = passes[p];
@@ -382,9 +408,10 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
             }
             if (e == hipSuccess && nOutside_[ps.eye]) {
                 b.tileList = tileListDev_ + listOffOutside_[ps.eye];
-                e = launch_easu_outside((int)in.format, -1, (int)out.format, b, nOutside_[ps.eye], ps.cnt, stream);
+                e = launch_easu_outside((int)in.format, -1, (int)out.format, b, nOutside_[ps.eye], ps.cnt, aux);
             }
         }
+        Join(stream);
     }
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("EASU launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;
@@ -444,6 +471,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
         FillEasu(ea, in, inStride, out, outStride, firstEye, alternate);
         EyePass passes[2];
         const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
+        hipStream_t aux = Fork(stream);
         for (int p = 0; p < np && e == hipSuccess; ++p) {
             const EyePass &ps = passes[p];
             FusedArgs fb = a;
@@ -457,9 +485,10 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
             }
             if (e == hipSuccess && nOutside_[ps.eye]) {
                 eb.tileList = tileListDev_ + listOffOutside_[ps.eye];
-                e = launch_easu_outside((int)in.format, (int)IntermediateFormat(), (int)out.format, eb, nOutside_[ps.eye], ps.cnt, stream);
+                e = launch_easu_outside((int)in.format, (int)IntermediateFormat(), (int)out.format, eb, nOutside_[ps.eye], ps.cnt, aux);
             }
         }
+        Join(stream);
     }
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("fused EASU+RCAS launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;

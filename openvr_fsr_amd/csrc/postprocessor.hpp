@@ -72,6 +72,12 @@ private:
     uint32_t nInside_[2] = {0, 0}, nOutside_[2] = {0, 0};
     size_t listOffInside_[2] = {0, 0}, listOffOutside_[2] = {0, 0};
     bool listsShared_ = false; // both eyes have identical lists
+    // the memory-bound outside-tile kernel and the VALU-bound inside-tile kernel are independent: the former runs on
+    // a ctx-owned auxiliary stream, forked from and joined back into the caller's stream with events
+    hipStream_t auxStream_ = nullptr;
+    hipEvent_t evFork_ = nullptr, evJoin_ = nullptr;
+    hipStream_t Fork(hipStream_t user);
+    void Join(hipStream_t user);
     int nisCellsW_ = 0, nisCellsH_ = 0;
 
     // ctx-owned device buffers: upscaledTexture / sharpenedTexture, PostProcessor.h:43-45,58-59
