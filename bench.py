@@ -32,6 +32,7 @@ WORKLOADS = {
     "C3": (1683, 1869, 2244, 2492, torch.uint8, 2.0, 1),     # NIS scaler (built-in USM sharpen)
     "C4": (2244, 2492, 2916, 3240, torch.uint8, 2.0, 0),     # renderScale 1.3 batch
     "C5": (2370, 2370, 3160, 3160, torch.float16, 0.5, 0),   # radius-masked, RGBA16F packed I/O
+    "C2r": (1683, 1869, 2244, 2492, torch.uint8, 0.5, 0),    # C2's shape with the reference's shipped radius 0.5 (openvr_mod.cfg)
 }
 
 
@@ -110,8 +111,8 @@ def measured_traffic(workload, kernel, n_img):
     path = os.path.join(ROOT, "profiles", "traffic_per_eye.json")
     try:
         per_eye = json.load(open(path))[workload]
-        hit = [v for k, v in per_eye.items() if k.endswith("::" + kernel)]
-        return int(hit[0]["hbm_bytes_per_eye"] * n_img) if hit else None
+        hit = [v for k, v in per_eye.items() if any(k.endswith("::" + part) for part in kernel.split("+"))]
+        return int(sum(h["hbm_bytes_per_eye"] for h in hit) * n_img) if hit else None
     except (OSError, KeyError, ValueError):
         return None
 
