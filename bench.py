@@ -228,7 +228,7 @@ def main():
                 "note": "the kernel is VALU-issue-bound on this chip (see DESIGN.md); frac is reported against the HBM roof the contract names"}
 
     cpu = None
-    if rank == 0 and not args.no_cpu and not use_nis and dtype == torch.uint8:
+    if rank == 0 and world == 1 and not args.no_cpu and not use_nis and dtype == torch.uint8:  # CPU baseline: N=1 only
         cpu = cpu_baseline(inW, inH, outW, outH, sharpness)
 
     if rank == 0:
