@@ -83,6 +83,7 @@ struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) mi
     const float *coefUsm;
     int32_t cellsW, cellsH; // LDS luma/edge tile extent of the scaler (incl. 3-texel ring)
     uint32_t tilesX, tilesY;
+    const uint32_t *tileList; // optional mask-sorted group list (see EasuArgs)
 };
 
 } // namespace ovrfsr

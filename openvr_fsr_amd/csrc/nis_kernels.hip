@@ -62,10 +62,24 @@ static hipError_t sharpen_go(bool strict, const NisArgs &a, dim3 grid, hipStream
     default: return hipErrorInvalidValue;                                                                \
     }
 
-hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s)
+template <int I, int O>
+static hipError_t nis_outside_go(const NisArgs &a, dim3 grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((ovrfsr_fast::nis_outside_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_t nGroups, uint32_t batch, hipStream_t s)
+{
+    if (!a.tileList || nGroups == 0) return hipErrorInvalidValue;
+    const dim3 grid(nGroups, 1, batch);
+    OVRFSR_DISPATCH_FMT(nis_outside_go, a, grid, s)
+}
+
+hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s, uint32_t nGroups)
 {
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
-    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    const dim3 grid(a.tileList ? nGroups : a.tilesX * a.tilesY, 1, batch);
     const size_t lds = nis_scaler_lds_bytes(a.cellsW, a.cellsH);
     OVRFSR_DISPATCH_FMT(scaler_go, prec == PREC_FP32_STRICT, a, grid, lds, s)
 }

@@ -238,7 +238,12 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
     }
     if (doUpscale_ && !cfg_.use_nis && cfg_.precision == OVRFSR_PRECISION_FP32 &&
         (maskMode_[0] == MASK_MIXED || maskMode_[1] == MASK_MIXED)) {
-        int rc = PrepareTileLists();
+        int rc = PrepareTileLists(kTileW, kTileH, 16, 16);
+        if (rc != OVRFSR_OK) return rc;
+    }
+    if (doUpscale_ && cfg_.use_nis && cfg_.precision == OVRFSR_PRECISION_FP32 &&
+        (maskMode_[0] == MASK_MIXED || maskMode_[1] == MASK_MIXED)) {
+        int rc = PrepareTileLists(32, 24, 32, 24); // NVScaler: one workgroup per 32x24 mask group
         if (rc != OVRFSR_OK) return rc;
     }
     if (doSharpen_ && !cfg_.use_nis) PrepareSharpeningResources();
@@ -265,18 +270,19 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
 
 // The radius mask is static per eye, so the tiles are sorted once on the host: tiles with at least one 16x16 group
 // inside the radius (EASU kernel, LDS-staged) and tiles entirely outside (bilinear only, LDS-free kernel).
-int PostProcessor::PrepareTileLists()
+int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t groupW, uint32_t groupH)
 {
-    const uint32_t tx = (outputWidth_ + kTileW - 1) / kTileW, ty = (outputHeight_ + kTileH - 1) / kTileH;
+    const uint32_t tx = (outputWidth_ + tileW - 1) / tileW, ty = (outputHeight_ + tileH - 1) / tileH;
+    const uint32_t gpx = tileW / groupW, gpy = tileH / groupH; // mask groups per tile
     std::vector<uint32_t> lists;
     std::vector<uint32_t> in[2], outl[2];
     for (int eye = 0; eye < 2; ++eye) {
         for (uint32_t t = 0; t < tx * ty; ++t) {
             const uint32_t tyi = t / tx, txi = t - tyi * tx;
             bool any = false;
-            for (uint32_t g = 0; g < 4 && !any; ++g) {
-                const uint32_t gx = 2 * txi + (g & 1u), gy = 2 * tyi + (g >> 1);
-                const uint32_t cx = (gx << 4) + 8u, cy = (gy << 4) + 8u;
+            for (uint32_t g = 0; g < gpx * gpy && !any; ++g) {
+                const uint32_t gx = gpx * txi + (g % gpx), gy = gpy * tyi + (g / gpx);
+                const uint32_t cx = gx * groupW + groupW / 2, cy = gy * groupH + groupH / 2;
                 const uint32_t ax = centre_[eye][0] - cx, ay = centre_[eye][1] - cy, bx = centre_[eye][2] - cx, by = centre_[eye][3] - cy;
                 any = (ax * ax + ay * ay <= radius_[1]) || (bx * bx + by * by <= radius_[1]);
             }
@@ -384,7 +390,30 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
         FillNis(na, firstEye, alternate);
         na.tilesX = (out.width + 31) / 32;   // Dispatch(ceil(outW/32), ceil(outH/24)), :397
         na.tilesY = (out.height + 23) / 24;
-        hipError_t e = launch_nis_scaler(cfg_.precision, (int)in.format, (int)out.format, na, n, stream);
+        na.tileList = nullptr;
+        hipError_t e = hipSuccess;
+        if (!tileListDev_) {
+            e = launch_nis_scaler(cfg_.precision, (int)in.format, (int)out.format, na, n, stream);
+        } else {
+            EyePass passes[2];
+            const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
+            hipStream_t aux = Fork(stream);
+            for (int p = 0; p < np && e == hipSuccess; ++p) {
+                NisArgs b = na;
+                const EyePass &ps = passes[p];
+                b.v.in += ps.inOff; b.v.out += ps.outOff; b.v.in_stride = ps.inStride; b.v.out_stride = ps.outStride;
+                if (ps.split) { b.m.first_eye = (uint32_t)ps.eye; b.m.alternate = 0; }
+                if (nInside_[ps.eye]) {
+                    b.tileList = tileListDev_ + listOffInside_[ps.eye];
+                    e = launch_nis_scaler(cfg_.precision, (int)in.format, (int)out.format, b, ps.cnt, stream, nInside_[ps.eye]);
+                }
+                if (e == hipSuccess && nOutside_[ps.eye]) {
+                    b.tileList = tileListDev_ + listOffOutside_[ps.eye];
+                    e = launch_nis_outside((int)in.format, (int)out.format, b, nOutside_[ps.eye], ps.cnt, aux);
+                }
+            }
+            Join(stream);
+        }
         if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("NVScaler launch: ") + hipGetErrorString(e));
         return OVRFSR_OK;
     }
@@ -503,6 +532,7 @@ int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, cons
         FillNis(na, firstEye, alternate);
         na.tilesX = (out.width + 31) / 32;   // Dispatch(ceil(outW/32), ceil(outH/32)), :492
         na.tilesY = (out.height + 31) / 32;
+        na.tileList = nullptr;
         hipError_t e = launch_nis_sharpen(cfg_.precision, (int)in.format, (int)out.format, na, n, stream);
         if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("NVSharpen launch: ") + hipGetErrorString(e));
         return OVRFSR_OK;

@@ -95,7 +95,7 @@ private:
     int PrepareResources(const ovrfsr_image &in);                         // :498-561
     void PrepareUpscalingResources();                                    // :285-383
     void PrepareSharpeningResources();                                   // :409-481
-    int PrepareTileLists();
+    int PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t groupW, uint32_t groupH);
     struct EyePass { int eye; uint32_t cnt; size_t inOff, outOff, inStride, outStride; bool split; };
     int EyePasses(uint32_t n, int firstEye, int alternate, size_t inStride, size_t outStride, EyePass out[2]) const;
     void FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStride, const ovrfsr_image &out, size_t outStride, int firstEye, int alternate) const;

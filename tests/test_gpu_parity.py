@@ -218,6 +218,31 @@ def test_nis_scaler_fp32_tolerance(gpu, iw, ih, ow, oh, gen):
     assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
 
 
+@pytest.mark.parametrize("radius,proj,debug", [(0.5, (0.5, 0.5, 0.5, 0.5), 0), (0.62, (0.42, 0.55, 0.61, 0.47), 1), (0.05, (0.5,) * 4, 0)])
+def test_nis_scaler_masked_product_lists(gpu, radius, proj, debug):
+    """Product build with a radius: mask-sorted group lists, LDS-free DirectCopy kernel on the auxiliary stream, and a
+    batch whose eyes have different centres.  Outside groups must be bit-identical to the strict build (DirectCopy has
+    no contraction-sensitive thresholds left after mad_unfused), inside groups within the NIS product tolerance."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 300, 240, 400, 320
+    imgs = np.stack([synth.structured_u8(iw, ih, 80 + i) for i in range(4)])
+    pp = A.PostProcessor(fsr_enabled=1, use_nis=1, out_width=ow, out_height=oh, sharpness=0.6, radius=radius,
+                         proj_centre=proj, debug_mode=debug, precision=FP32)
+    outs = torch.empty((4, oh, ow, 4), dtype=torch.float32, device="cuda")
+    pp.apply_batch(torch.from_numpy(imgs).cuda(), outs, first_eye=1, alternate_eyes=True)
+    torch.cuda.synchronize()
+    got = outs.cpu().numpy()
+    pp.close()
+    for i in range(4):
+        want = _nis_oracle_upscale(imgs[i], ow, oh, 0.6, radius, proj, 1 ^ (i & 1), debug)
+        err = np.abs(got[i] - want)
+        assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (i, float((err <= 1e-3).mean()), float(err.max()))
+    one = run_gpu(imgs[0], ow, oh, np.float32, eye=1, precision=FP32, use_nis=1, sharpness=0.6, radius=radius,
+                  proj_centre=proj, debug_mode=debug)
+    assert np.array_equal(one, got[0])
+
+
 def test_nis_rejects_out_of_range_scale(gpu):
     import openvr_fsr_amd as A
     with pytest.raises(A.OvrFsrError):
