@@ -23,7 +23,7 @@ namespace ovrfsr_strict {
 namespace ovrfsr {
 
 int nis_pitch(int cellsW) { return cellsW <= 32 ? 32 : cellsW <= 40 ? 40 : 0; }
-size_t nis_scaler_lds_bytes(int cellsW, int cellsH) { return (size_t)nis_pitch(cellsW) * cellsH * (4 + 4 + 16) + 2 * 512 * 4; }
+size_t nis_scaler_lds_bytes(int cellsW, int cellsH) { return (size_t)nis_pitch(cellsW) * cellsH * (4 + 4 + 16 + 4) + 2 * 512 * 4; } // Yu, Y255, E, raw texel
 
 template <int I, int O>
 static hipError_t scaler_go(bool strict, const NisArgs &a, dim3 grid, size_t lds, hipStream_t s)
