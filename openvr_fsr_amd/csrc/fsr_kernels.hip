@@ -134,9 +134,29 @@ static hipError_t easu_outside_go(int mid_fmt, const EasuArgs &a, dim3 grid, hip
 // nTiles blocks, each resolving tile a.tileList[block]: tiles entirely outside the radius (product build only).
 // mid_fmt < 0: EASU pass only; mid_fmt >= 0: write the FINAL pixel of the EASU->RCAS pipeline (RCAS outside the radius
 // is a tinted copy of the intermediate texel, so the intermediate's format rounding is applied in registers).
+// RGBA8 -> RGBA8, upscaling only: LDS-staged, 4 pixels per thread (see outside_rgba8_kernel)
+bool outside_rgba8_ok(const BatchView &v) { return v.inW <= v.outW && v.inH <= v.outH; }
+
+hipError_t launch_outside_rgba8(int tileH, int mode, const OutsideArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s)
+{
+    if (!a.tileList || !a.bilX || !a.bilY || nTiles == 0 || !outside_rgba8_ok(a.v)) return hipErrorInvalidValue;
+    const dim3 grid(nTiles, 1, batch);
+#define OVRFSR_OUTSIDE_CASE(TH, M) \
+    if (tileH == TH && mode == M) { hipLaunchKernelGGL((ovrfsr_fast::outside_rgba8_kernel<TH, M>), grid, dim3(8 * TH), 0, s, a); return hipGetLastError(); }
+    OVRFSR_OUTSIDE_CASE(32, OUTSIDE_PLAIN) OVRFSR_OUTSIDE_CASE(32, OUTSIDE_MID8) OVRFSR_OUTSIDE_CASE(32, OUTSIDE_TINT)
+    OVRFSR_OUTSIDE_CASE(24, OUTSIDE_TINT)
+#undef OVRFSR_OUTSIDE_CASE
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s)
 {
     if (!a.tileList || nTiles == 0) return hipErrorInvalidValue;
+    if (in_fmt == FMT_RGBA8 && out_fmt == FMT_RGBA8 && mid_fmt != FMT_RGBA16F && outside_rgba8_ok(a.v)) {
+        OutsideArgs o;
+        o.v = a.v; o.tilesX = a.tilesX; o.tileList = a.tileList; o.bilX = a.bilX; o.bilY = a.bilY; o.debug = a.debug;
+        return launch_outside_rgba8(kTileH, mid_fmt < 0 ? OUTSIDE_PLAIN : mid_fmt == FMT_RGBA8 ? OUTSIDE_MID8 : OUTSIDE_TINT, o, nTiles, batch, s);
+    }
     const dim3 grid(nTiles, 1, batch);
     OVRFSR_DISPATCH_FMT(easu_outside_go, mid_fmt, a, grid, s)
 }

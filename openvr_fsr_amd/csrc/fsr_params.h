@@ -50,6 +50,19 @@ struct EasuArgs {
     uint32_t debug;           // RCAS const0[3]; only read by the "final" outside kernel (tinted copy of the fused path)
 };
 
+// RGBA8 -> RGBA8 bilinear fallback / DirectCopy of mask-sorted tiles entirely outside the radius (product build)
+enum : int { OUTSIDE_PLAIN = 0,  // EASU pass only: bilinear, alpha = 1                       (fsr_easu.hlsl:33-36)
+             OUTSIDE_MID8 = 1,   // final pixel: tint(UNORM8-rounded bilinear)               (+ fsr_rcas.hlsl:46-47)
+             OUTSIDE_TINT = 2 }; // final pixel: tint(bilinear): float intermediate, or NIS DirectCopy (NIS_Upscale.hlsl:77-90)
+struct OutsideArgs {
+    BatchView v;
+    uint32_t tilesX;          // tiles (32 x TH output pixels) per row
+    const uint32_t *tileList;
+    const BilinTap *bilX;     // host-built column / row taps (see BilinTap), padded by 64 entries
+    const BilinTap *bilY;
+    uint32_t debug;
+};
+
 struct RcasArgs {
     BatchView v;
     float sharp;            // FsrRcasCon con[0] as float
@@ -84,6 +97,8 @@ struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) mi
     int32_t cellsW, cellsH; // LDS luma/edge tile extent of the scaler (incl. 3-texel ring)
     uint32_t tilesX, tilesY;
     const uint32_t *tileList; // optional mask-sorted group list (see EasuArgs)
+    const BilinTap *bilX;     // DirectCopy taps of the mask-sorted outside kernel (see OutsideArgs)
+    const BilinTap *bilY;
 };
 
 } // namespace ovrfsr

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "fsr_launch.h"
@@ -37,6 +38,10 @@ PostProcessor::PostProcessor(int device, const ovrfsr_config &cfg) : device_(dev
 
 hipStream_t PostProcessor::Fork(hipStream_t user)
 {
+    // diagnostic: OVRFSR_SERIAL=1 keeps both kernels of a masked pass on the caller's stream (stand-alone kernel
+    // durations for profiling; the product default overlaps them)
+    static const bool serial = [] { const char *e = std::getenv("OVRFSR_SERIAL"); return e && e[0] == '1'; }();
+    if (serial) return user;
     if (!auxStream_) {
         if (hipStreamCreateWithFlags(&auxStream_, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&evFork_, hipEventDisableTiming) != hipSuccess ||
@@ -215,10 +220,10 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
         const size_t lds = easu_lds_bytes(cfg_.precision, (int)in.format, cellsW_, cellsH_);
         if (lds > 64 * 1024) return Fail(OVRFSR_ERR_UNSUPPORTED, "scale ratio needs more LDS than one tile may use");
     }
-    if (doUpscale_ && !cfg_.use_nis) {
-        // column / row taps of the bilinear fallback (SampleLevel at pos/outSize, 8-bit sub-texel snap): same IEEE
+    if (doUpscale_) {
+        // column / row taps of the bilinear fallback / NIS DirectCopy (SampleLevel at pos/outSize, 8-bit sub-texel snap): same IEEE
         // operations as fsr_device.inc's bilinear_uv / fixed8, evaluated once per column and row instead of per pixel
-        std::vector<BilinTap> taps((size_t)ow + oh);
+        std::vector<BilinTap> taps((size_t)ow + oh + 64); // padding: kernels read whole quads / clamp-free rows
         auto fill = [](BilinTap *t, uint32_t outN, uint32_t inN) {
             for (uint32_t o = 0; o < outN; ++o) {
                 volatile float u = (float)o / (float)outN;
@@ -355,6 +360,7 @@ void PostProcessor::FillNis(NisArgs &a, int firstEye, int alternate) const
     a.coefScale = nisCoefDev_;
     a.coefUsm = nisCoefDev_ + 512;
     a.cellsW = nisCellsW_; a.cellsH = nisCellsH_;
+    a.bilX = bilinDev_; a.bilY = bilinDev_ ? bilinDev_ + outputWidth_ : nullptr;
 }
 
 void PostProcessor::FillMask(MaskArgs &m, int firstEye, int alternate) const
