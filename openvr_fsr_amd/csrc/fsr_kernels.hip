@@ -170,11 +170,12 @@ hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uin
     OVRFSR_DISPATCH_FMT(easu_go, strict, a, grid, lds, s)
 }
 
-hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uint32_t batch, hipStream_t s)
+hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const bool strict = prec == PREC_FP32_STRICT;
-    const dim3 grid(a.tilesX * a.tilesY, 1, batch);
+    if (a.tileList && (strict || nTiles == 0)) return hipErrorInvalidValue; // lists are a product-build feature
+    const dim3 grid(a.tileList ? nTiles : a.tilesX * a.tilesY, 1, batch);
     OVRFSR_DISPATCH_FMT(rcas_go, strict, a, grid, s)
 }
 

@@ -48,6 +48,8 @@ struct EasuArgs {
     const BilinTap *bilY;
     const uint32_t *tileList; // optional: tile index of each block (mask-sorted launch); null = all tiles in XCD order
     uint32_t debug;           // RCAS const0[3]; only read by the "final" outside kernel (tinted copy of the fused path)
+    float rcpOutW, rcpOutH;   // RN(1/outW), RN(1/outH): o/out as mul + 2 fma (Markstein), see div_exact
+    uint32_t rcpExact;        // host verified that form against IEEE division for every o < outW (outH); else 0
 };
 
 // RGBA8 -> RGBA8 bilinear fallback / DirectCopy of mask-sorted tiles entirely outside the radius (product build)
@@ -69,6 +71,7 @@ struct RcasArgs {
     uint32_t debug;         // const0[3]
     MaskArgs m;
     uint32_t tilesX, tilesY;
+    const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs); product build only
 };
 
 struct FusedArgs {

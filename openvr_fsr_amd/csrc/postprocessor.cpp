@@ -220,6 +220,22 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
         const size_t lds = easu_lds_bytes(cfg_.precision, (int)in.format, cellsW_, cellsH_);
         if (lds > 64 * 1024) return Fail(OVRFSR_ERR_UNSUPPORTED, "scale ratio needs more LDS than one tile may use");
     }
+    {
+        // o/outW, o/outH of the bilinear fallback as a multiply and two FMAs: verify against IEEE division for every o
+        auto check = [](uint32_t n, float &rn) {
+            volatile float r = 1.0f / (float)n;
+            rn = r;
+            for (uint32_t o = 0; o < n; ++o) {
+                const float q0 = (float)o * rn;
+                const float rem = std::fma(-q0, (float)n, (float)o);
+                volatile float want = (float)o / (float)n;
+                if (std::fma(rem, rn, q0) != want) return false;
+            }
+            return true;
+        };
+        const bool okW = check(ow, rcpOut_[0]), okH = check(oh, rcpOut_[1]);
+        rcpExact_ = okW && okH;
+    }
     if (doUpscale_) {
         // column / row taps of the bilinear fallback / NIS DirectCopy (SampleLevel at pos/outSize, 8-bit sub-texel snap): same IEEE
         // operations as fsr_device.inc's bilinear_uv / fixed8, evaluated once per column and row instead of per pixel
@@ -259,7 +275,14 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
     // radius need no intermediate at all); unmasked ones stay two-pass (VALU-bound, the ring recompute costs 9 %)
     const bool autoFused = cfg_.fused == -1 && tileListDev_ != nullptr && fusedCellsW_ <= 40 &&
                            fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) <= 160 * 1024;
-    if ((cfg_.fused == 1 || autoFused) && doUpscale_ && doSharpen_ && !cfg_.use_nis) {
+    // auto on a masked product-build EASU+RCAS pipeline: the two-pass kernels on the tiles touching the radius, tiles
+    // outside written in final form (ApplySorted); cfg.fused = 1 keeps the single fused kernel on those tiles
+    // Measured: with 4-byte pixels the sorted two-pass form wins (C2 shape, radius 0.5: +13 %); with 8/16-byte
+    // pixels the frame is HBM-write-bound, the intermediate's extra traffic and the longer dependent chain lose to the
+    // fused kernel (C5: -15 %), so those keep it.
+    useSorted_ = cfg_.fused == -1 && tileListDev_ != nullptr && doUpscale_ && doSharpen_ && !cfg_.use_nis &&
+                 in.format == OVRFSR_FORMAT_RGBA8_UNORM && IntermediateFormat() == OVRFSR_FORMAT_RGBA8_UNORM;
+    if ((cfg_.fused == 1 || (autoFused && !useSorted_)) && doUpscale_ && doSharpen_ && !cfg_.use_nis) {
         const bool pitchOk = cfg_.precision == OVRFSR_PRECISION_FP32_STRICT || fusedCellsW_ <= 40;
         if (!pitchOk || fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) > 160 * 1024)
             return Fail(OVRFSR_ERR_UNSUPPORTED, "fused kernel: tile footprint does not fit LDS at this scale");
@@ -294,6 +317,16 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
             (any ? in[eye] : outl[eye]).push_back(t);
         }
     }
+    std::vector<uint32_t> ring[2];
+    for (int eye = 0; eye < 2; ++eye) {
+        std::vector<uint8_t> isIn(tx * ty, 0);
+        for (uint32_t t : in[eye]) isIn[t] = 1;
+        for (uint32_t t : outl[eye]) {
+            const uint32_t tyi = t / tx, txi = t - tyi * tx;
+            const bool adj = (txi > 0 && isIn[t - 1]) || (txi + 1 < tx && isIn[t + 1]) || (tyi > 0 && isIn[t - tx]) || (tyi + 1 < ty && isIn[t + tx]);
+            if (adj) ring[eye].push_back(t);
+        }
+    }
     listsShared_ = in[0] == in[1];
     // block b of a launch goes to XCD b % 8: hand every XCD a contiguous run of the (row-major) list
     auto xcd_order = [](std::vector<uint32_t> &v) {
@@ -307,6 +340,8 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
         nInside_[eye] = (uint32_t)in[eye].size(); nOutside_[eye] = (uint32_t)outl[eye].size();
         listOffInside_[eye] = lists.size(); lists.insert(lists.end(), in[eye].begin(), in[eye].end());
         listOffOutside_[eye] = lists.size(); lists.insert(lists.end(), outl[eye].begin(), outl[eye].end());
+        nRing_[eye] = (uint32_t)ring[eye].size();
+        listOffRing_[eye] = lists.size(); lists.insert(lists.end(), ring[eye].begin(), ring[eye].end());
     }
     if (lists.empty()) return OVRFSR_OK;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&tileListDev_), lists.size() * sizeof(uint32_t));
@@ -463,6 +498,7 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
     a.bilX = bilinDev_; a.bilY = bilinDev_ + outputWidth_;
     a.tileList = nullptr;
     a.debug = rcasCon_[3];
+    a.rcpOutW = rcpOut_[0]; a.rcpOutH = rcpOut_[1]; a.rcpExact = rcpExact_ ? 1u : 0u;
     a.tilesX = (out.width + kTileW - 1) / kTileW;   // the reference dispatches 16x16 groups (PostProcessor.cpp:399);
     a.tilesY = (out.height + kTileH - 1) / kTileH;  // a tile here is 2x2 of those
 }
@@ -479,6 +515,76 @@ int PostProcessor::EyePasses(uint32_t n, int firstEye, int alternate, size_t inS
     for (int p = 0; p < 2; ++p)
         out[p] = EyePass{(firstEye & 1) ^ p, (n - p + 1) / 2, (size_t)p * inStride, (size_t)p * outStride, 2 * inStride, 2 * outStride, true};
     return 2;
+}
+
+// Masked EASU+RCAS, product build.  Main stream: EASU on the tiles touching the radius -> intermediate; the bilinear
+// intermediate of the outside tiles 4-adjacent to them (RCAS taps reach one pixel across a tile edge); RCAS on the same
+// tile list.  Auxiliary stream: every outside tile in final form.  The intermediate buffer is only ever touched at
+// inside + ring tiles.
+int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                               const ovrfsr_image &out, size_t outStride, hipStream_t stream)
+{
+    ovrfsr_image mid;
+    mid.width = outputWidth_; mid.height = outputHeight_;
+    mid.format = IntermediateFormat();
+    mid.pitch_bytes = outputWidth_ * texel_bytes(mid.format);
+    const size_t midStride = (size_t)mid.pitch_bytes * outputHeight_;
+    int rc = EnsureBuffer(&upscaled_, &upscaledBytes_, midStride * n);
+    if (rc != OVRFSR_OK) return rc;
+    mid.data = upscaled_;
+
+    EasuArgs toMid, toOut;
+    FillEasu(toMid, in, inStride, mid, midStride, firstEye, alternate);
+    FillEasu(toOut, in, inStride, out, outStride, firstEye, alternate);
+    RcasArgs ra;
+    ra.v = make_view(mid, midStride, out, outStride);
+    std::memcpy(&ra.sharp, &rcasCon_[0], 4);
+    ra.debug = rcasCon_[3];
+    FillMask(ra.m, firstEye, alternate);
+    ra.tilesX = toOut.tilesX; ra.tilesY = toOut.tilesY;
+    ra.tileList = nullptr;
+
+    EyePass passes[2], midPasses[2];
+    const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
+    EyePasses(n, firstEye, alternate, midStride, midStride, midPasses); // same split, strides of the intermediate
+    hipError_t e = hipSuccess;
+    hipStream_t aux = Fork(stream);
+    for (int p = 0; p < np && e == hipSuccess; ++p) {
+        const EyePass &ps = passes[p];
+        const EyePass &ms = midPasses[p];
+        EasuArgs em = toMid, eo = toOut;
+        RcasArgs rb = ra;
+        em.v.in += ps.inOff; em.v.in_stride = ps.inStride; em.v.out += ms.outOff; em.v.out_stride = ms.outStride;
+        eo.v.in += ps.inOff; eo.v.in_stride = ps.inStride; eo.v.out += ps.outOff; eo.v.out_stride = ps.outStride;
+        rb.v.in += ms.inOff; rb.v.in_stride = ms.inStride; rb.v.out += ps.outOff; rb.v.out_stride = ps.outStride;
+        if (ps.split) {
+            em.m.first_eye = eo.m.first_eye = rb.m.first_eye = (uint32_t)ps.eye;
+            em.m.alternate = eo.m.alternate = rb.m.alternate = 0;
+        }
+        const int eye = ps.eye;
+        // launch order matters for how the two hardware queues share the chip: the VALU-bound kernel first
+        if (nInside_[eye]) {
+            em.tileList = tileListDev_ + listOffInside_[eye];
+            e = launch_easu(cfg_.precision, (int)in.format, (int)mid.format, em, ps.cnt, stream, nInside_[eye]);
+        }
+        if (e == hipSuccess && nOutside_[eye]) {
+            eo.tileList = tileListDev_ + listOffOutside_[eye];
+            e = launch_easu_outside((int)in.format, (int)mid.format, (int)out.format, eo, nOutside_[eye], ps.cnt, aux);
+        }
+        if (e == hipSuccess && nInside_[eye]) {
+            if (nRing_[eye]) {
+                em.tileList = tileListDev_ + listOffRing_[eye];
+                e = launch_easu_outside((int)in.format, -1, (int)mid.format, em, nRing_[eye], ps.cnt, stream);
+            }
+            if (e == hipSuccess) {
+                rb.tileList = tileListDev_ + listOffInside_[eye];
+                e = launch_rcas(cfg_.precision, (int)mid.format, (int)out.format, rb, ps.cnt, stream, nInside_[eye]);
+            }
+        }
+    }
+    Join(stream);
+    if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("mask-sorted EASU+RCAS launch: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
 }
 
 int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
@@ -550,6 +656,7 @@ int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, cons
     FillMask(a.m, firstEye, alternate);
     a.tilesX = (out.width + kTileW - 1) / kTileW;
     a.tilesY = (out.height + kTileH - 1) / kTileH;
+    a.tileList = nullptr;
     hipError_t e = launch_rcas(cfg_.precision, (int)in.format, (int)out.format, a, n, stream);
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("RCAS launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;
@@ -561,7 +668,9 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
 {
     if (cfg_.debug_mode && evStart_) (void)hipEventRecord(evStart_, stream);
     int rc = OVRFSR_OK;
-    if (useFused_) {
+    if (useSorted_) {
+        rc = ApplySorted(n, firstEye, alternate, in, inStride, out, outStride, stream);
+    } else if (useFused_) {
         rc = ApplyFused(n, firstEye, alternate, in, inStride, out, outStride, stream);
     } else if (doUpscale_ && doSharpen_) {
         ovrfsr_image mid;

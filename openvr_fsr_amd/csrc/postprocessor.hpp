@@ -59,6 +59,8 @@ private:
     uint32_t centre_[2][4] = {};
     uint32_t radius_[4] = {};
     uint32_t maskMode_[2] = {};
+    float rcpOut_[2] = {0, 0}; // RN(1/outW), RN(1/outH) and whether mul+2fma reproduces o/out for every o (div_exact)
+    bool rcpExact_ = false;
     int cellsW_ = 0, cellsH_ = 0;
     int fusedCellsW_ = 0, fusedCellsH_ = 0; // footprint of the 34x34 EASU block of the fused kernel
     bool useFused_ = false;
@@ -69,8 +71,9 @@ private:
     // mask-sorted EASU tile lists (product build, masked configs): per eye, tiles with any group inside the radius
     // and tiles entirely outside; the latter run through an LDS-free kernel at twice the occupancy
     uint32_t *tileListDev_ = nullptr;
-    uint32_t nInside_[2] = {0, 0}, nOutside_[2] = {0, 0};
-    size_t listOffInside_[2] = {0, 0}, listOffOutside_[2] = {0, 0};
+    uint32_t nInside_[2] = {0, 0}, nOutside_[2] = {0, 0}, nRing_[2] = {0, 0};
+    size_t listOffInside_[2] = {0, 0}, listOffOutside_[2] = {0, 0}, listOffRing_[2] = {0, 0}; // ring: outside tiles 4-adjacent to an inside tile
+    bool useSorted_ = false;   // masked EASU+RCAS: two passes on the inside list, final-form outside tiles (ApplySorted)
     bool listsShared_ = false; // both eyes have identical lists
     // the memory-bound outside-tile kernel and the VALU-bound inside-tile kernel are independent: the former runs on
     // a ctx-owned auxiliary stream, forked from and joined back into the caller's stream with events
@@ -107,6 +110,8 @@ private:
                          const ovrfsr_image &out, size_t outStride, hipStream_t stream); // :563-638
     int ApplyUpscaling(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                        const ovrfsr_image &out, size_t outStride, hipStream_t stream);   // :385-401
+    int ApplySorted(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
+                    const ovrfsr_image &out, size_t outStride, hipStream_t stream);
     int ApplyFused(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                    const ovrfsr_image &out, size_t outStride, hipStream_t stream);
     int ApplySharpening(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,

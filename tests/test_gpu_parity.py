@@ -218,6 +218,24 @@ def test_nis_scaler_fp32_tolerance(gpu, iw, ih, ow, oh, gen):
     assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
 
 
+@pytest.mark.parametrize("debug", [0, 1])
+def test_masked_sorted_two_pass_float_out(gpu, debug):
+    """auto policy on a masked RGBA8 pipeline = EASU and RCAS on the tile list touching the radius, ring tiles'
+    intermediate, outside tiles in final form; here with a float32 destination (generic outside kernel) and the debug
+    tint, against the oracle's un-rounded final values."""
+    iw, ih, ow, oh = 330, 250, 440, 333
+    img8 = synth.structured_u8(iw, ih, 91)
+    proj = (0.45, 0.5, 0.55, 0.5)
+    _, wantf = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.7, radius=0.55, proj=proj, eye=1, debug=debug, want_float=True)
+    got = run_gpu(img8, ow, oh, np.float32, eye=1, precision=FP32, sharpness=0.7, radius=0.55, proj_centre=proj, debug_mode=debug)
+    err = np.abs(got - wantf)
+    # a 1-LSB flip of the UNORM8 intermediate (rare, see test_pipeline_fp32_tolerance) is amplified up to 4x by RCAS
+    assert (err <= 1e-4).mean() >= 0.999 and err.max() <= RCAS_LSB / 255.0, (float((err <= 1e-4).mean()), float(err.max()))
+    got8 = run_gpu(img8, ow, oh, np.uint8, eye=1, precision=FP32, sharpness=0.7, radius=0.55, proj_centre=proj, debug_mode=debug)
+    same = run_gpu(img8, ow, oh, np.uint8, eye=1, precision=FP32, sharpness=0.7, radius=0.55, proj_centre=proj, debug_mode=debug, fused=0)
+    assert np.array_equal(got8, same)   # sorted two-pass == plain two-pass with the same kernels
+
+
 @pytest.mark.parametrize("radius,proj,debug", [(0.5, (0.5, 0.5, 0.5, 0.5), 0), (0.62, (0.42, 0.55, 0.61, 0.47), 1), (0.05, (0.5,) * 4, 0)])
 def test_nis_scaler_masked_product_lists(gpu, radius, proj, debug):
     """Product build with a radius: mask-sorted group lists, LDS-free DirectCopy kernel on the auxiliary stream, and a
@@ -471,9 +489,10 @@ def test_masked_product_paths_agree(gpu, radius, proj, debug, fused):
         want = O.fsr_pipeline_u8(imgs[i], ow, oh, sharpness=0.8, radius=radius, proj=proj, eye=1 ^ (i & 1), debug=debug)
         mx, frac = lsb_stats(got[i], want)
         # outside the radius the pixel is a bilinear blend with 8-bit weights of byte texels: results land exactly on
-        # UNORM8 rounding ties far more often than EASU's, and the product build's contracted FMAs break such ties
-        # differently from the as-written evaluation -> allow 0.5 % of values to differ (still <= 5 LSB, typically 1)
-        assert mx <= RCAS_LSB and frac <= 5e-3, (i, mx, frac)
+        # UNORM8 rounding ties very often (5 % of bytes at scale 3/4), so the product build evaluates that blend
+        # unfused, exactly as written (bilerp_unfused): those pixels are bit-identical to the oracle and the whole
+        # frame meets the same bound as an unmasked one
+        assert mx <= RCAS_LSB and frac <= LSB_FRACTION, (i, mx, frac)
     # single image through apply() as well
     one = run_gpu(imgs[0], ow, oh, np.uint8, eye=1, precision=FP32, sharpness=0.8, radius=radius, proj_centre=proj,
                   debug_mode=debug, fused=fused)
