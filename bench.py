@@ -207,8 +207,8 @@ def main():
         ms_step = time_events(step, max(5, args.steps // 2), stream)
         masked_fsr = (radius < 2.0) and not use_nis
         if masked_fsr or use_nis:  # NVScaler is a single pass: the step is the kernel (+ its DirectCopy companion when masked)
-            # masked EASU+RCAS runs as ONE fused pipeline (fused_kernel on tiles touching the radius + easu_outside_kernel
-            # writing the rest in final form): the step itself is the dominant "kernel"
+            # masked EASU+RCAS runs as one mask-sorted pipeline (tiles touching the radius: EASU+RCAS or the fused kernel;
+            # the rest written in final form by a concurrent kernel): the step itself is the dominant "kernel"
             ms_easu = ms_step
             easu_bytes = algo_bytes_eye * n_img
         else:
@@ -221,7 +221,13 @@ def main():
             pe.close()
             easu_bytes = bpp * (inW * inH + outW * outH) * n_img
         ach = easu_bytes / (ms_easu * 1e-3) / 1e9
-        kname = ("nis_scaler_kernel+nis_outside_kernel" if radius < 2.0 else "nis_scaler_kernel") if use_nis else ("fused_kernel+easu_outside_kernel" if masked_fsr else "easu_fast_kernel")
+        rgba8 = dtype == torch.uint8
+        if use_nis:   # NVScaler (+ the DirectCopy kernel of the groups outside the radius, concurrent)
+            kname = "nis_scaler_kernel" + (("+outside_rgba8_kernel" if rgba8 else "+nis_outside_kernel") if radius < 2.0 else "")
+        elif masked_fsr:  # tiles touching the radius: EASU+RCAS (RGBA8) or the fused kernel; the rest in final form, concurrent
+            kname = "easu_fast_kernel+rcas_direct_kernel+outside_rgba8_kernel" if rgba8 else "fused_kernel+easu_outside_kernel"
+        else:
+            kname = "easu_fast_kernel"
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, kname, n_img),
                 "launch_ms": round(ms_easu, 4), "algorithmic_bytes_per_launch": easu_bytes,

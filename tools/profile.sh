@@ -35,7 +35,7 @@ def parse(fn):
     d = {}
     for line in open(os.path.join(out, fn)):
         m = re.match(r"void (ovrfsr_\w+::\w+)<.*?mean=\s*([\d.]+)", line)
-        if m: d[m.group(1)] = float(m.group(2)) * 1024.0
+        if m: d[m.group(1)] = d.get(m.group(1), 0.0) + float(m.group(2)) * 1024.0  # template instances summed
     return d
 f, w = parse("pmc_FETCH_SIZE.txt"), parse("pmc_WRITE_SIZE.txt")
 res = {k: {"fetch_bytes_per_eye": 2 * f[k] / 8, "write_bytes_per_eye": w.get(k, 0) / 8,
