@@ -102,3 +102,86 @@ def test_batch_with_stride_gaps_and_formats(gpu):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
     pp.close()
+
+
+def _outside_px(ow, oh, centre, r2, gw, gh):
+    """bool [oh, ow]: pixel lies in a gw x gh mask group that fails the radius test (uint32 wrap-around arithmetic of
+    fsr_easu.hlsl:41-45 / NIS_Upscale.hlsl:98-101)."""
+    gx = (np.arange(ow, dtype=np.uint32) // gw) * np.uint32(gw) + np.uint32(gw // 2)
+    gy = (np.arange(oh, dtype=np.uint32) // gh) * np.uint32(gh) + np.uint32(gh // 2)
+    c = np.asarray(centre, np.uint32)
+    with np.errstate(over="ignore"):
+        d1 = (c[0] - gx)[None, :] ** 2 + ((c[1] - gy) ** 2)[:, None]
+        d2 = (c[2] - gx)[None, :] ** 2 + ((c[3] - gy) ** 2)[:, None]
+    return ~((d1 <= np.uint32(r2)) | (d2 <= np.uint32(r2)))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_masked_product_fuzz(gpu, seed):
+    """Product build, radius-masked, every pipeline form (mask-sorted two-pass = auto, plain two-pass, fused): pixels
+    of mask groups outside the radius are bit-identical to the oracle (unfused bilinear), pixels inside stay within the
+    RCAS-amplified LSB bound; padded row pitches are respected.  Sizes span one to ~100 tiles, scales 0.5..0.99 and a few
+    minifications (which take the generic outside kernel)."""
+    import torch
+    import openvr_fsr_amd as A
+    rng = np.random.default_rng(3000 + seed)
+    iw, ih = int(rng.integers(20, 330)), int(rng.integers(20, 330))
+    s = float(rng.choice([0.5, 0.501, 0.67, 0.75, 0.77, 0.9, 0.99, rng.uniform(0.5, 1.0), 1.15]))
+    ow, oh = max(8, int(iw / s)), max(8, int(ih / s))
+    if s < 1:
+        ow, oh = max(ow, iw + 1), max(oh, ih + 1)
+    radius = float(rng.uniform(0.1, 0.9))
+    proj = tuple(float(x) for x in rng.uniform(0.3, 0.7, 4))
+    eye, debug, sharp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(0, 1))
+    img8 = [synth.structured_u8, synth.random_u8][seed % 2](iw, ih, seed)
+    want = O.fsr_pipeline_u8(img8, ow, oh, sharpness=sharp, radius=radius, proj=proj, eye=eye, debug=debug)
+    centre, rad = O.mask_constants(ow, oh, radius, proj, True, eye)
+    outside = _outside_px(ow, oh, centre, rad[1], 16, 16)
+    pad_in, pad_out = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+    big_in = torch.zeros((ih, iw + pad_in, 4), dtype=torch.uint8, device="cuda")
+    big_in[:, :iw] = torch.from_numpy(img8).cuda()
+    big_out = torch.empty((oh, ow + pad_out, 4), dtype=torch.uint8, device="cuda")
+    for fused in (-1, 0, 1):
+        try:
+            pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=sharp, radius=radius, proj_centre=proj,
+                                 debug_mode=debug, precision=FP32, fused=fused)
+            big_out.fill_(99)
+            got = pp.apply(eye, big_in[:, :iw], out=big_out[:, :ow]).cpu().numpy()
+        except A.OvrFsrError:
+            assert fused == 1 and s > 1   # the fused kernel's tile footprint does not fit LDS when minifying
+            continue
+        finally:
+            pp.close()
+        assert np.array_equal(got[outside], want[outside]), (fused, iw, ih, ow, oh, radius, int((got[outside] != want[outside]).sum()))
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 5, (fused, iw, ih, ow, oh, int(d.max()))
+        if pad_out:
+            assert (big_out[:, ow:].cpu().numpy() == 99).all(), "wrote outside the output image"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_nis_masked_product_fuzz(gpu, seed):
+    """NVScaler with a radius, product build: DirectCopy groups (mask-sorted, outside_rgba8_kernel for RGBA8 destinations,
+    nis_outside_kernel otherwise) are bit-identical to the oracle."""
+    import openvr_fsr_amd as A
+    from tests.util import run_gpu
+    rng = np.random.default_rng(4000 + seed)
+    iw, ih = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+    s = float(rng.choice([0.5, 0.67, 0.75, 0.9, 0.99, rng.uniform(0.5, 1.0)]))
+    ow, oh = min(2 * iw, max(iw + 1, int(iw / s))), min(2 * ih, max(ih + 1, int(ih / s)))
+    radius = float(rng.uniform(0.1, 0.9))
+    proj = tuple(float(x) for x in rng.uniform(0.3, 0.7, 4))
+    eye, debug, sharp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(0, 1))
+    img8 = [synth.structured_u8, synth.random_u8][seed % 2](iw, ih, seed)
+    cs, cu = A.nis_coefs()
+    ok, cfg = A.nis_scaler_config(sharp, iw, ih, ow, oh)
+    assert ok
+    centre, rad = O.mask_constants(ow, oh, radius, proj, True, eye)
+    want = O.nis_upscale(O.unorm8_to_float(img8), ow, oh, O.nis_block(cfg, centre, rad, debug), cs, cu)
+    outside = _outside_px(ow, oh, centre, rad[1], 32, 24)
+    kw = dict(eye=eye, precision=FP32, use_nis=1, sharpness=sharp, radius=radius, proj_centre=proj, debug_mode=debug)
+    got8 = run_gpu(img8, ow, oh, np.uint8, **kw)
+    assert np.array_equal(got8[outside], O.float_to_unorm8(want)[outside]), (iw, ih, ow, oh, radius)
+    gotf = run_gpu(img8, ow, oh, np.float32, **kw)
+    assert np.array_equal(gotf[outside].view(np.uint32), want[outside].view(np.uint32)), (iw, ih, ow, oh, radius)
+    assert np.abs(gotf - want).max() <= 0.05
