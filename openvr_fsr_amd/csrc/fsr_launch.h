@@ -14,8 +14,8 @@ hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uin
 int nis_pitch(int cellsW);
 size_t nis_scaler_lds_bytes(int cellsW, int cellsH);
 hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s, uint32_t nGroups = 0);
-bool outside_rgba8_ok(const BatchView &v);
-hipError_t launch_outside_rgba8(int tileH, int mode, const OutsideArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s);
+bool outside_staged_ok(const BatchView &v, int in_fmt);
+hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt, const OutsideArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s);
 hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_t nGroups, uint32_t batch, hipStream_t s);
 hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s);
 } // namespace ovrfsr

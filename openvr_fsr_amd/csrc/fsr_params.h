@@ -52,10 +52,8 @@ struct EasuArgs {
     uint32_t rcpExact;        // host verified that form against IEEE division for every o < outW (outH); else 0
 };
 
-// RGBA8 -> RGBA8 bilinear fallback / DirectCopy of mask-sorted tiles entirely outside the radius (product build)
-enum : int { OUTSIDE_PLAIN = 0,  // EASU pass only: bilinear, alpha = 1                       (fsr_easu.hlsl:33-36)
-             OUTSIDE_MID8 = 1,   // final pixel: tint(UNORM8-rounded bilinear)               (+ fsr_rcas.hlsl:46-47)
-             OUTSIDE_TINT = 2 }; // final pixel: tint(bilinear): float intermediate, or NIS DirectCopy (NIS_Upscale.hlsl:77-90)
+// LDS-staged bilinear fallback / DirectCopy of mask-sorted tiles entirely outside the radius (product build,
+// outside_staged_kernel)
 struct OutsideArgs {
     BatchView v;
     uint32_t tilesX;          // tiles (32 x TH output pixels) per row

@@ -72,10 +72,10 @@ static hipError_t nis_outside_go(const NisArgs &a, dim3 grid, hipStream_t s)
 hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_t nGroups, uint32_t batch, hipStream_t s)
 {
     if (!a.tileList || nGroups == 0) return hipErrorInvalidValue;
-    if (in_fmt == FMT_RGBA8 && out_fmt == FMT_RGBA8 && a.bilX && outside_rgba8_ok(a.v)) {
+    if (a.bilX && a.bilY && outside_staged_ok(a.v, in_fmt)) {
         OutsideArgs o;
         o.v = a.v; o.tilesX = a.tilesX; o.tileList = a.tileList; o.bilX = a.bilX; o.bilY = a.bilY; o.debug = a.reserved1 != 0.0f ? 1u : 0u;
-        return launch_outside_rgba8(24, OUTSIDE_TINT, o, nGroups, batch, s);
+        return launch_outside_staged(24, in_fmt, FMT_RGBA32F, out_fmt, o, nGroups, batch, s);
     }
     const dim3 grid(nGroups, 1, batch);
     OVRFSR_DISPATCH_FMT(nis_outside_go, a, grid, s)
