@@ -145,16 +145,17 @@ bool outside_staged_ok(const BatchView &v, int in_fmt) { return v.inW <= v.outW 
 template <int TH, int I, int O>
 static hipError_t outside_staged_go(int mid_fmt, const OutsideArgs &a, dim3 grid, hipStream_t s)
 {
+    [[maybe_unused]] const size_t lds = (size_t)a.lds_cols * a.lds_rows * 16;
     if constexpr (I != FMT_RGBA8) {
         return hipErrorInvalidValue;
     } else if constexpr (TH == 24) { // NIS DirectCopy
-        hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<24, I, O, FMT_RGBA32F>), grid, dim3(8 * 24), 0, s, a);
+        hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<24, I, O, FMT_RGBA32F>), grid, dim3(8 * 24), lds, s, a);
     } else {
         switch (mid_fmt) {
-        case FMT_RGBA8: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA8>), grid, dim3(256), 0, s, a); break;
-        case FMT_RGBA16F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA16F>), grid, dim3(256), 0, s, a); break;
-        case FMT_RGBA32F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA32F>), grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, -1>), grid, dim3(256), 0, s, a); break;
+        case FMT_RGBA8: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA8>), grid, dim3(256), lds, s, a); break;
+        case FMT_RGBA16F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA16F>), grid, dim3(256), lds, s, a); break;
+        case FMT_RGBA32F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA32F>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, -1>), grid, dim3(256), lds, s, a); break;
         }
     }
     return hipGetLastError();
@@ -165,6 +166,7 @@ template <int I, int O> static hipError_t outside_staged_go24(int mid_fmt, const
 hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt, const OutsideArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s)
 {
     if (!a.tileList || !a.bilX || !a.bilY || nTiles == 0 || !outside_staged_ok(a.v, in_fmt)) return hipErrorInvalidValue;
+    if (a.lds_cols < 2 || a.lds_cols > 36 || a.lds_rows < 2 || a.lds_rows > 34) return hipErrorInvalidValue;
     const dim3 grid(nTiles, 1, batch);
     if (tileH == 24) { OVRFSR_DISPATCH_FMT(outside_staged_go24, mid_fmt, a, grid, s) }
     if (tileH != 32) return hipErrorInvalidValue;
@@ -178,6 +180,7 @@ hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuA
     if (a.bilX && a.bilY && outside_staged_ok(a.v, in_fmt)) {
         OutsideArgs o;
         o.v = a.v; o.tilesX = a.tilesX; o.tileList = a.tileList; o.bilX = a.bilX; o.bilY = a.bilY; o.debug = a.debug;
+        o.lds_cols = a.outsideCols; o.lds_rows = a.outsideRows;
         return launch_outside_staged(kTileH, in_fmt, mid_fmt, out_fmt, o, nTiles, batch, s);
     }
     const dim3 grid(nTiles, 1, batch);

@@ -48,6 +48,7 @@ struct EasuArgs {
     const BilinTap *bilY;
     const uint32_t *tileList; // optional: tile index of each block (mask-sorted launch); null = all tiles in XCD order
     uint32_t debug;           // RCAS const0[3]; only read by the "final" outside kernel (tinted copy of the fused path)
+    uint32_t outsideCols, outsideRows; // largest bilinear footprint of a 32x32 tile (outside_staged_kernel's LDS plane)
     float rcpOutW, rcpOutH;   // RN(1/outW), RN(1/outH): o/out as mul + 2 fma (Markstein), see div_exact
     uint32_t rcpExact;        // host verified that form against IEEE division for every o < outW (outH); else 0
 };
@@ -61,6 +62,7 @@ struct OutsideArgs {
     const BilinTap *bilX;     // host-built column / row taps (see BilinTap), padded by 64 entries
     const BilinTap *bilY;
     uint32_t debug;
+    uint32_t lds_cols, lds_rows; // LDS texel plane extent (set by launch_outside_staged from the tap tables' host copy)
 };
 
 struct RcasArgs {
@@ -100,6 +102,7 @@ struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) mi
     const uint32_t *tileList; // optional mask-sorted group list (see EasuArgs)
     const BilinTap *bilX;     // DirectCopy taps of the mask-sorted outside kernel (see OutsideArgs)
     const BilinTap *bilY;
+    uint32_t outsideCols, outsideRows; // largest bilinear footprint of a 32x24 group
 };
 
 } // namespace ovrfsr

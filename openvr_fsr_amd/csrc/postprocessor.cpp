@@ -1,6 +1,7 @@
 // postprocessor.cpp -- see postprocessor.hpp.  Reference: src/postprocess/PostProcessor.cpp.
 #include "postprocessor.hpp"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -253,6 +254,18 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
         };
         fill(taps.data(), ow, in.width);
         fill(taps.data() + ow, oh, in.height);
+        // largest [first tap, last tap + 1] span of a tile: the LDS plane of the staged outside-tile kernel
+        auto span = [](const BilinTap *t, uint32_t outN, uint32_t tile) {
+            int best = 2;
+            for (uint32_t o0 = 0; o0 < outN; o0 += tile) {
+                const uint32_t o1 = o0 + tile - 1 < outN ? o0 + tile - 1 : outN - 1;
+                best = std::max(best, t[o1].i0 + 2 - t[o0].i0);
+            }
+            return (uint32_t)best;
+        };
+        outsideCols_ = span(taps.data(), ow, 32);
+        outsideRows_[0] = span(taps.data() + ow, oh, 32);
+        outsideRows_[1] = span(taps.data() + ow, oh, 24);
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&bilinDev_), taps.size() * sizeof(BilinTap));
         if (e == hipSuccess) e = hipMemcpy(bilinDev_, taps.data(), taps.size() * sizeof(BilinTap), hipMemcpyHostToDevice);
         if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("bilinear tap tables: ") + hipGetErrorString(e));
@@ -396,6 +409,7 @@ void PostProcessor::FillNis(NisArgs &a, int firstEye, int alternate) const
     a.coefUsm = nisCoefDev_ + 512;
     a.cellsW = nisCellsW_; a.cellsH = nisCellsH_;
     a.bilX = bilinDev_; a.bilY = bilinDev_ ? bilinDev_ + outputWidth_ : nullptr;
+    a.outsideCols = outsideCols_; a.outsideRows = outsideRows_[1];
 }
 
 void PostProcessor::FillMask(MaskArgs &m, int firstEye, int alternate) const
@@ -499,6 +513,7 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
     a.tileList = nullptr;
     a.debug = rcasCon_[3];
     a.rcpOutW = rcpOut_[0]; a.rcpOutH = rcpOut_[1]; a.rcpExact = rcpExact_ ? 1u : 0u;
+    a.outsideCols = outsideCols_; a.outsideRows = outsideRows_[0];
     a.tilesX = (out.width + kTileW - 1) / kTileW;   // the reference dispatches 16x16 groups (PostProcessor.cpp:399);
     a.tilesY = (out.height + kTileH - 1) / kTileH;  // a tile here is 2x2 of those
 }

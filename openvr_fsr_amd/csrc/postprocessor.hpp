@@ -59,6 +59,7 @@ private:
     uint32_t centre_[2][4] = {};
     uint32_t radius_[4] = {};
     uint32_t maskMode_[2] = {};
+    uint32_t outsideCols_ = 0, outsideRows_[2] = {0, 0}; // bilinear footprint bound of a 32-wide tile; rows for 32- and 24-row tiles
     float rcpOut_[2] = {0, 0}; // RN(1/outW), RN(1/outH) and whether mul+2fma reproduces o/out for every o (div_exact)
     bool rcpExact_ = false;
     int cellsW_ = 0, cellsH_ = 0;
