@@ -66,6 +66,7 @@ void PostProcessor::Join(hipStream_t user)
 PostProcessor::~PostProcessor()
 {
     Reset();
+    DeviceGuard guard(device_);
     if (auxStream_) (void)hipStreamDestroy(auxStream_);
     if (evFork_) (void)hipEventDestroy(evFork_);
     if (evJoin_) (void)hipEventDestroy(evJoin_);
@@ -81,6 +82,7 @@ int PostProcessor::Fail(int status, const std::string &what)
 
 void PostProcessor::Reset()
 {
+    DeviceGuard guard(device_); // resources live on the ctx's device, whatever the caller has selected
     enabled_ = true;
     initialized_ = false;
     if (upscaled_) (void)hipFree(upscaled_);
@@ -89,7 +91,7 @@ void PostProcessor::Reset()
     if (bilinDev_) (void)hipFree(bilinDev_);
     if (tileListDev_) (void)hipFree(tileListDev_);
     tileListDev_ = nullptr;
-    nInside_[0] = nInside_[1] = nOutside_[0] = nOutside_[1] = 0;
+    nInside_[0] = nInside_[1] = nOutside_[0] = nOutside_[1] = nRing_[0] = nRing_[1] = 0;
     nisCoefDev_ = nullptr;
     bilinDev_ = nullptr;
     upscaled_ = sharpened_ = nullptr;
