@@ -299,6 +299,32 @@ def test_c3_full_size_nis(gpu):
     assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (float((err <= 1e-3).mean()), float(err.max()))
 
 
+def test_c2_c3_full_size_shipped_radius(gpu):
+    """C2 / C3 shapes with the reference's shipped radius 0.5 (openvr_mod.cfg), product build, auto policy: mask-sorted
+    two-pass (FSR) / group lists (NIS) with the LDS-staged outside kernel on the auxiliary stream.  Pixels of mask groups
+    outside the radius are bit-identical to the oracle, the frame meets the unmasked bounds."""
+    from tests.test_gpu_fuzz import _outside_px
+    iw, ih, ow, oh = 1683, 1869, 2244, 2492
+    img8 = synth.structured_u8(iw, ih, synth.seed_for(1, 0))
+    centre, rad = O.mask_constants(ow, oh, 0.5)
+    want8 = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9, radius=0.5)
+    got8 = run_gpu(img8, ow, oh, np.uint8, precision=FP32, sharpness=0.9, radius=0.5)
+    outside = _outside_px(ow, oh, centre, rad[1], 16, 16)
+    assert 0.7 < outside.mean() < 0.85
+    assert np.array_equal(got8[outside], want8[outside])
+    mx, frac = lsb_stats(got8, want8)
+    assert mx <= RCAS_LSB and frac <= LSB_FRACTION, (mx, frac)
+    import openvr_fsr_amd as A
+    cs, cu = A.nis_coefs()
+    ok, cfg = A.nis_scaler_config(0.9, iw, ih, ow, oh)
+    wantn = O.float_to_unorm8(O.nis_upscale(O.unorm8_to_float(img8), ow, oh, O.nis_block(cfg, centre, rad, 0), cs, cu))
+    gotn = run_gpu(img8, ow, oh, np.uint8, precision=FP32, use_nis=1, sharpness=0.9, radius=0.5)
+    outside = _outside_px(ow, oh, centre, rad[1], 32, 24)
+    assert np.array_equal(gotn[outside], wantn[outside])
+    d = np.abs(gotn.astype(np.int16) - wantn.astype(np.int16))
+    assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
+
+
 def test_c4_c5_shapes_properties(gpu):
     """C4 (2244x2492 -> 2916x3240) and C5 (radius-masked 3160x3160, RGBA16F I/O): size-independent properties."""
     import torch
