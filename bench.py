@@ -149,8 +149,8 @@ def cpu_baseline(inW, inH, outW, outH, sharpness):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per GPU per step")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "strict"])

@@ -524,3 +524,40 @@ def test_masked_product_paths_agree(gpu, radius, proj, debug, fused):
     one = run_gpu(imgs[0], ow, oh, np.uint8, eye=1, precision=FP32, sharpness=0.8, radius=radius, proj_centre=proj,
                   debug_mode=debug, fused=fused)
     assert np.array_equal(one, got[0])
+
+
+@pytest.mark.parametrize("dtype,radius,nis", [(np.uint8, 2.0, 0), (np.uint8, 0.5, 0), (np.float16, 0.5, 0), (np.uint8, 0.5, 1)])
+def test_hip_graph_capture_and_replay(gpu, dtype, radius, nis):
+    """Once its lazy resources exist (one warm call), apply_batch is only kernel launches plus the event fork/join of the
+    auxiliary stream, so it can be captured into a HIP graph on the caller's stream and replayed: same bytes as the
+    direct call, for the unmasked, mask-sorted two-pass, fused + outside and NIS group-list pipelines."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 150, 120, 200, 160
+    imgs8 = np.stack([synth.structured_u8(iw, ih, 30 + i) for i in range(4)])
+    imgs = imgs8 if dtype == np.uint8 else (imgs8.astype(np.float32) / 255.0).astype(np.float16)
+    tdt = torch.uint8 if dtype == np.uint8 else torch.float16
+    t = torch.from_numpy(imgs).cuda()
+    pp = A.PostProcessor(fsr_enabled=1, use_nis=nis, out_width=ow, out_height=oh, sharpness=0.8, radius=radius,
+                         proj_centre=(0.45, 0.5, 0.55, 0.5))
+    ref = torch.empty((4, oh, ow, 4), dtype=tdt, device="cuda")
+    out = torch.zeros_like(ref)
+    pp.apply_batch(t, ref, first_eye=0, alternate_eyes=True)      # also builds the lazy resources
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            pp.apply_batch(t, out, first_eye=0, alternate_eyes=True)
+    torch.cuda.synchronize()
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    t.copy_(torch.flip(t, dims=[0]))                              # new input in the same buffers, replay again
+    pp.apply_batch(t, ref, first_eye=0, alternate_eyes=True)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    pp.close()
