@@ -163,13 +163,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local_rank)          # before the process group: its collectives must use THIS rank's GPU
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL: only the timing barrier / max-reduce use it
 
     import openvr_fsr_amd as A
     inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
@@ -188,7 +188,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
