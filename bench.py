@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+CLOCK_RAMP_S = 0.3      # untimed sustained load before the warm-up steps (see main)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable by a float4 copy
 
 WORKLOADS = {
@@ -191,6 +192,13 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    # clock ramp: a cold MI355X takes ~50 ms of sustained load to reach its steady clocks (20 steps after 3 warm-up
+    # steps read 5 % low); run the step for a fixed wall time first so that short --warmup values measure the same
+    # steady state as long ones.  Untimed, before the W warm-up steps; recorded in the JSON line.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < CLOCK_RAMP_S:
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     dt = max_over_ranks(timed_region(step, args.steps, barrier), world, dev)
@@ -250,7 +258,7 @@ def main():
             "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, %s, sharpness 0.9, radius %.1f"
                                    % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F",
                                       "NIS NVScaler" if use_nis else "EASU+RCAS (UNORM8 intermediate)", radius),
-                       "pairs_per_gpu_per_step": args.pairs, "precision": args.precision,
+                       "pairs_per_gpu_per_step": args.pairs, "precision": args.precision, "clock_ramp_s": CLOCK_RAMP_S,
                        "parallelism": "batch sharded over %d GPU(s), no collective" % world},
             "roofline": roof, "cpu_baseline": cpu,
         }
