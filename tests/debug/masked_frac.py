@@ -1,4 +1,4 @@
-# tools/debug/masked_frac.py -- fraction of bytes of a radius-masked product-build frame that differ from the oracle
+# tests/debug/masked_frac.py -- fraction of bytes of a radius-masked product-build frame that differ from the oracle
 import sys; sys.path.insert(0, '.')
 import numpy as np
 from tests import synth
