@@ -76,3 +76,42 @@ def test_create_without_gpu_reports_no_device():
     assert A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx)) == 4   # OVRFSR_ERR_NO_DEVICE: no CPU fallback
     with pytest.raises(K.OvrFsrError):
         A.PostProcessor(fsr_enabled=1)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing in the product package or its shared library may import, link or call
+    it, and outside tests/ only bench.py's cpu_baseline() and __graft_entry__.smoke() may."""
+    import ast
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_importers(path):
+        """names of the functions (or '<module>') of a python file that import the oracle package"""
+        tree = ast.parse(open(path).read())
+        hits = []
+        for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+            body = fn.body if isinstance(fn, ast.Module) else fn.body
+            for node in body if isinstance(fn, ast.Module) else ast.walk(fn):
+                if isinstance(node, ast.ImportFrom) and (node.module or "").split(".")[0] == "oracle":
+                    hits.append(getattr(fn, "name", "<module>"))
+                if isinstance(node, ast.Import) and any(a.name.split(".")[0] == "oracle" for a in node.names):
+                    hits.append(getattr(fn, "name", "<module>"))
+        return sorted(set(hits))
+
+    allowed = {"bench.py": ["cpu_baseline"], "__graft_entry__.py": ["smoke"]}
+    for dirpath, dirs, files in os.walk(root):
+        dirs[:] = [d for d in dirs if d not in (".git", "tests", "oracle", "gpurun_out", "ab", "__pycache__", "build")]
+        for f in files:
+            if f.endswith(".py"):
+                rel = os.path.relpath(os.path.join(dirpath, f), root)
+                assert oracle_importers(os.path.join(dirpath, f)) == allowed.get(rel, []), rel
+    lib = os.path.join(root, "openvr_fsr_amd", "libopenvr_fsr_amd.so")
+    needed = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
+    syms = subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout
+    assert "ovo_" not in syms and "ref_" not in syms.replace("_ref_count", "")
+    for src in os.listdir(os.path.join(root, "openvr_fsr_amd", "csrc")):
+        if src.endswith((".cpp", ".hpp", ".h", ".hip", ".inc")):
+            text = open(os.path.join(root, "openvr_fsr_amd", "csrc", src)).read()
+            assert '../../oracle' not in text and 'liboracle' not in text, src
