@@ -101,9 +101,13 @@ typedef struct ovrfsr_config {
     int32_t quantize_intermediate; /* 1 = EASU result is stored as UNORM8 before RCAS reads it,
                                 as the reference's R8G8B8A8_UNORM intermediate texture does
                                 (PostProcessor.cpp:348); 0 = intermediate kept in float          */
-    int32_t fused;           /* -1 auto, 0 two kernels through an HBM intermediate, 1 one kernel
-                                with the intermediate in LDS (same results for the same
-                                quantize_intermediate)                                           */
+    int32_t fused;           /* 0 two kernels through an HBM intermediate, 1 one kernel with the
+                                intermediate in LDS (same results for the same quantize_intermediate
+                                up to the product build's rounding), -1 auto: whichever is faster
+                                for the configuration (two kernels unmasked; with a radius mask the
+                                tiles outside the radius are written in final form by a concurrent
+                                kernel and the tiles touching it take the two-kernel form for RGBA8
+                                pipelines, the fused one for half / float)                       */
     int32_t stage_mask;      /* 0 = the reference's stage selection (upscale iff scale != 1, sharpen
                                 iff !use_nis || scale == 1; PostProcessor.cpp:586-594).  1 = upscale
                                 stage only (BASELINE config C1 "EASU-only"), 2 = sharpen stage only  */

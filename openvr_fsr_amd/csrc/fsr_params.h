@@ -82,7 +82,6 @@ struct FusedArgs {
     MaskArgs m;
     int32_t cellsW, cellsH;
     uint32_t tilesX, tilesY;
-    uint32_t quantize;      // informational: the intermediate format is a template parameter of fused_kernel
     const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs)
 };
 

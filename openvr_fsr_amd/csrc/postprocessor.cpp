@@ -617,7 +617,6 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
     a.cellsW = fusedCellsW_; a.cellsH = fusedCellsH_;
     a.tilesX = (out.width + kTileW - 1) / kTileW;
     a.tilesY = (out.height + kTileH - 1) / kTileH;
-    a.quantize = cfg_.quantize_intermediate ? 1u : 0u;
     a.tileList = nullptr;
     hipError_t e = hipSuccess;
     if (!tileListDev_) {
