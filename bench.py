@@ -35,6 +35,8 @@ WORKLOADS = {
     "C5": (2370, 2370, 3160, 3160, torch.float16, 0.5, 0),   # radius-masked, RGBA16F packed I/O
     "C2r": (1683, 1869, 2244, 2492, torch.uint8, 0.5, 0),    # C2's shape with the reference's shipped radius 0.5 (openvr_mod.cfg)
     "C3r": (1683, 1869, 2244, 2492, torch.uint8, 0.5, 1),    # C3 (NIS) with the shipped radius 0.5
+    "C2s": (2244, 2492, 2244, 2492, torch.uint8, 2.0, 0),    # renderScale 1: RCAS only (PostProcessor.cpp:586-594)
+    "C3s": (2244, 2492, 2244, 2492, torch.uint8, 2.0, 1),    # renderScale 1 with useNis: NVSharpen only
 }
 
 
@@ -214,7 +216,8 @@ def main():
     if rank == 0:
         ms_step = time_events(step, max(5, args.steps // 2), stream)
         masked_fsr = (radius < 2.0) and not use_nis
-        if masked_fsr or use_nis:  # NVScaler is a single pass: the step is the kernel (+ its DirectCopy companion when masked)
+        sharpen_only = (inW, inH) == (outW, outH)   # renderScale 1: RCAS / NVSharpen alone
+        if masked_fsr or use_nis or sharpen_only:  # single-pass forms: the step is the kernel (+ its concurrent companion when masked)
             # masked EASU+RCAS runs as one mask-sorted pipeline (tiles touching the radius: EASU+RCAS or the fused kernel;
             # the rest written in final form by a concurrent kernel): the step itself is the dominant "kernel"
             ms_easu = ms_step
@@ -230,7 +233,9 @@ def main():
             easu_bytes = bpp * (inW * inH + outW * outH) * n_img
         ach = easu_bytes / (ms_easu * 1e-3) / 1e9
         rgba8 = dtype == torch.uint8
-        if use_nis:   # NVScaler (+ the DirectCopy kernel of the groups outside the radius, concurrent)
+        if sharpen_only:
+            kname = "nis_sharpen_kernel" if use_nis else "rcas_direct_kernel"
+        elif use_nis:   # NVScaler (+ the DirectCopy kernel of the groups outside the radius, concurrent)
             kname = "nis_scaler_kernel" + (("+outside_rgba8_kernel" if rgba8 else "+nis_outside_kernel") if radius < 2.0 else "")
         elif masked_fsr:  # tiles touching the radius: EASU+RCAS (RGBA8) or the fused kernel; the rest in final form, concurrent
             kname = "easu_fast_kernel+rcas_direct_kernel+outside_rgba8_kernel" if rgba8 else "fused_kernel+easu_outside_kernel"
@@ -257,7 +262,8 @@ def main():
             "data": "synthetic (%s)" % args.content,
             "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, %s, sharpness 0.9, radius %.1f"
                                    % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F",
-                                      "NIS NVScaler" if use_nis else "EASU+RCAS (UNORM8 intermediate)", radius),
+                                      ("NIS NVSharpen" if (inW, inH) == (outW, outH) else "NIS NVScaler") if use_nis else
+                                      ("RCAS" if (inW, inH) == (outW, outH) else "EASU+RCAS (UNORM8 intermediate)"), radius),
                        "pairs_per_gpu_per_step": args.pairs, "precision": args.precision, "clock_ramp_s": CLOCK_RAMP_S,
                        "parallelism": "batch sharded over %d GPU(s), no collective" % world},
             "roofline": roof, "cpu_baseline": cpu,
