@@ -203,6 +203,21 @@ def test_nis_sharpen_strict_bit_exact(gpu, w, h, gen, radius, debug):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "max abs diff %g" % np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("w,h,gen,radius,debug", [(128, 107, synth.structured_u8, 2.0, 0), (83, 83, synth.extremes_u8, 0.6, 1),
+                                                   (200, 150, synth.random_u8, 2.0, 0)])
+def test_nis_sharpen_fp32_tolerance(gpu, w, h, gen, radius, debug):
+    """NVSharpen, product build: exact wave-uniform skips of zero-weight directional terms + contraction.  Same statistical
+    bound as NVScaler (hard edge thresholds); UNORM8 outputs 99.9 % within 1 LSB."""
+    img8 = gen(w, h, 31)
+    want = _nis_oracle_sharpen(img8, 0.75, radius, debug=debug)
+    got = run_gpu(img8, w, h, np.float32, precision=FP32, use_nis=1, render_scale=1.0, sharpness=0.75, radius=radius, debug_mode=debug)
+    err = np.abs(got - want)
+    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (float((err <= 1e-3).mean()), float(err.max()))
+    got8 = run_gpu(img8, w, h, np.uint8, precision=FP32, use_nis=1, render_scale=1.0, sharpness=0.75, radius=radius, debug_mode=debug)
+    d = np.abs(got8.astype(np.int16) - O.float_to_unorm8(want).astype(np.int16))
+    assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
+
+
 @pytest.mark.parametrize("iw,ih,ow,oh,gen", NIS_SHAPES)
 def test_nis_scaler_fp32_tolerance(gpu, iw, ih, ow, oh, gen):
     # NIS is full of hard thresholds (GetEdgeMap, phase quantisation): the product build (FMA contraction,
