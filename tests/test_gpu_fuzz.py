@@ -185,3 +185,17 @@ def test_nis_masked_product_fuzz(gpu, seed):
     gotf = run_gpu(img8, ow, oh, np.float32, **kw)
     assert np.array_equal(gotf[outside].view(np.uint32), want[outside].view(np.uint32)), (iw, ih, ow, oh, radius)
     assert np.abs(gotf - want).max() <= 0.05
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh", [(12288, 6, 16384, 8), (6, 12288, 8, 16384), (16383, 3, 16384, 5), (1, 1, 2, 2), (3, 2, 4, 3)])
+def test_extreme_shapes(gpu, iw, ih, ow, oh):
+    """The largest dimension the ABI accepts (16384) as thin strips, and the smallest images: strict build bit-exact,
+    product build within 5 LSB, masked and unmasked (footprints, tile lists and tap tables at their extremes)."""
+    from tests.util import run_gpu
+    img8 = synth.random_u8(iw, ih, 5)
+    for radius in (2.0, 0.4):
+        want = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.6, radius=radius)
+        got = run_gpu(img8, ow, oh, np.uint8, precision=STRICT, sharpness=0.6, radius=radius)
+        assert np.array_equal(got, want), (radius,)
+        gotp = run_gpu(img8, ow, oh, np.uint8, precision=FP32, sharpness=0.6, radius=radius)
+        assert np.abs(gotp.astype(np.int16) - want.astype(np.int16)).max() <= 5, (radius,)
