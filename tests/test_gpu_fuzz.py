@@ -199,3 +199,20 @@ def test_extreme_shapes(gpu, iw, ih, ow, oh):
         assert np.array_equal(got, want), (radius,)
         gotp = run_gpu(img8, ow, oh, np.uint8, precision=FP32, sharpness=0.6, radius=radius)
         assert np.abs(gotp.astype(np.int16) - want.astype(np.int16)).max() <= 5, (radius,)
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh", [(12288, 6, 16384, 8), (6, 12288, 8, 16384), (3, 2, 4, 3)])
+def test_extreme_shapes_nis(gpu, iw, ih, ow, oh):
+    import openvr_fsr_amd as A
+    from tests.util import run_gpu
+    img8 = synth.random_u8(iw, ih, 6)
+    cs, cu = A.nis_coefs()
+    ok, cfg = A.nis_scaler_config(0.5, iw, ih, ow, oh)
+    assert ok
+    for radius in (2.0, 0.4):
+        centre, rad = O.mask_constants(ow, oh, radius)
+        want = O.nis_upscale(O.unorm8_to_float(img8), ow, oh, O.nis_block(cfg, centre, rad, 0), cs, cu)
+        got = run_gpu(img8, ow, oh, np.float32, precision=STRICT, use_nis=1, sharpness=0.5, radius=radius)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (radius,)
+        gotp = run_gpu(img8, ow, oh, np.float32, precision=FP32, use_nis=1, sharpness=0.5, radius=radius)
+        assert np.abs(gotp - want).max() <= 0.05, (radius,)
