@@ -576,3 +576,22 @@ def test_hip_graph_capture_and_replay(gpu, dtype, radius, nis):
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
     pp.close()
+
+
+def test_plain_c_caller(gpu, tmp_path):
+    """examples/headless (plain C11, built by __graft_entry__.build()): create, apply both eyes with a ctx-owned output,
+    debug-mode GPU time, PPM capture -- the C ABI end to end without Python in the loop."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "headless")
+    if not os.path.exists(exe):
+        pytest.skip("examples/headless not built")
+    ppm = str(tmp_path / "eye.ppm")
+    r = subprocess.run([exe, "-", ppm], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("eye ")]
+    assert len(lines) == 6 and all("1683x1869 -> 2244x2492" in l and " ms on the GPU" in l for l in lines), r.stdout
+    data = open(ppm, "rb").read()
+    assert data.startswith(b"P6\n2244 2492\n255\n") and len(data) == len(b"P6\n2244 2492\n255\n") + 2244 * 2492 * 3
+    px = np.frombuffer(data[len(b"P6\n2244 2492\n255\n"):], np.uint8)
+    assert px.std() > 10    # an image, not a constant
