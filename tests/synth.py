@@ -12,7 +12,7 @@ def structured_u8(w, h, seed):
     rng = np.random.default_rng(seed)
     y, x = np.mgrid[0:h, 0:w].astype(np.float32)
     ph = rng.uniform(0, 6.28, 3).astype(np.float32)
-    img = np.empty((h, w, 4), np.float32)
+    img = np.ones((h, w, 4), np.float32)
     for c in range(3):
         img[..., c] = 0.5 + 0.35 * np.sin(x * (0.011 + 0.004 * c) + ph[c]) * np.cos(y * (0.008 + 0.003 * c) - ph[c])
     period = max(16, min(w, h) // 6)

@@ -216,3 +216,31 @@ def test_extreme_shapes_nis(gpu, iw, ih, ow, oh):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (radius,)
         gotp = run_gpu(img8, ow, oh, np.float32, precision=FP32, use_nis=1, sharpness=0.5, radius=radius)
         assert np.abs(gotp - want).max() <= 0.05, (radius,)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_masked_product_fuzz_half(gpu, seed):
+    """RGBA16F in / RGBA16F out with a radius (BASELINE C5's form), product build, auto and explicit pipeline forms:
+    half intermediate, fused kernel on the tiles touching the radius, per-pixel outside kernel.  Strict build bit-exact,
+    product build within the half-float tolerance of test_c4_c5_shapes_properties."""
+    from tests.util import run_gpu
+    rng = np.random.default_rng(5000 + seed)
+    iw, ih = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+    s = float(rng.choice([0.5, 0.67, 0.75, 0.9, rng.uniform(0.5, 1.0)]))
+    ow, oh = max(iw + 1, int(iw / s)), max(ih + 1, int(ih / s))
+    radius = float(rng.uniform(0.15, 0.9))
+    proj = tuple(float(x) for x in rng.uniform(0.3, 0.7, 4))
+    eye, debug, sharp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(0, 1))
+    img8 = [synth.structured_u8, synth.random_u8][seed % 2](iw, ih, seed)
+    imgh = (img8.astype(np.float32) / 255.0).astype(np.float16)
+    centre, rad = O.mask_constants(ow, oh, radius, proj, True, eye)
+    e = O.easu(imgh.astype(np.float32), ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
+    e16 = e.astype(np.float16).astype(np.float32)                       # half-float intermediate texture
+    want = O.rcas(e16, O.rcas_con(sharp, debug), centre, rad).astype(np.float16)
+    kw = dict(eye=eye, sharpness=sharp, radius=radius, proj_centre=proj, debug_mode=debug)
+    got = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, **kw)
+    assert np.array_equal(got, want), (iw, ih, ow, oh, radius)
+    for fused in (-1, 0, 1):
+        got = run_gpu(imgh, ow, oh, np.float16, precision=FP32, fused=fused, **kw).astype(np.float32)
+        err = np.abs(got - want.astype(np.float32))
+        assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 2e-2, (fused, float((err <= 1e-3).mean()), float(err.max()))
