@@ -147,7 +147,12 @@ OVRFSR_API int ovrfsr_output_size(const ovrfsr_config *cfg, uint32_t in_width, u
  *           selects the store conversion).  When the ctx is a pass-through (fsr disabled, or the
  *           second Submit of a shared texture, PostProcessor.cpp:155-158) *out describes the
  *           image the compositor should receive and nothing is launched.
- *   stream  hipStream_t (NULL = default stream).  Launches are asynchronous on it.
+ *   stream  hipStream_t (NULL = default stream).  Launches are asynchronous on it.  A ctx owns scratch device
+ *           memory (the EASU->RCAS intermediate, its output image) and an auxiliary stream that is forked from
+ *           and joined back into `stream` with events: consecutive calls on one ctx must be ordered by the
+ *           caller -- same stream, or synchronised streams -- exactly like draws on one D3D11 immediate context.
+ *           After the first call for a given input size a call allocates nothing and can be captured into a
+ *           HIP graph.
  * (Re)builds constants on first use and whenever the input size changes (PostProcessor.cpp:136-153). */
 OVRFSR_API int ovrfsr_apply(ovrfsr_ctx *ctx, int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds,
                             ovrfsr_image *out, void *stream);
