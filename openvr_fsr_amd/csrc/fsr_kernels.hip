@@ -1,6 +1,7 @@
 // fsr_kernels.hip -- instantiates the gfx950 FSR1 kernels twice (product build and strict
 // validation build, see fsr_kernels.inc) and exposes typed launchers to the host launch manager.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "fsr_params.h"
 #include "fsr_launch.h"
 
