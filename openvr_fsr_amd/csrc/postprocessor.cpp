@@ -289,14 +289,14 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
     // one launch with the intermediate in LDS only on request: on this chip both stages are VALU-bound and the ring
     // recompute costs more than the HBM round trip saves, so auto (-1) means two kernels
     useFused_ = false;
-    // auto: masked product-build pipelines run fused + mask-sorted (they are HBM-write-bound, and tiles outside the
+    // auto: masked product-build pipelines run fused + mask-sorted (most of their pixels are plain bilinear copies, and tiles outside the
     // radius need no intermediate at all); unmasked ones stay two-pass (VALU-bound, the ring recompute costs 9 %)
     const bool autoFused = cfg_.fused == -1 && tileListDev_ != nullptr && fusedCellsW_ <= 40 &&
                            fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) <= 160 * 1024;
     // auto on a masked product-build EASU+RCAS pipeline: the two-pass kernels on the tiles touching the radius, tiles
     // outside written in final form (ApplySorted); cfg.fused = 1 keeps the single fused kernel on those tiles
     // Measured: with 4-byte pixels the sorted two-pass form wins (C2 shape, radius 0.5: +13 %); with 8/16-byte
-    // pixels the frame is HBM-write-bound, the intermediate's extra traffic and the longer dependent chain lose to the
+    // pixels the outside kernel dominates the frame, and the three dependent launches of the sorted form lose to the
     // fused kernel (C5: -15 %), so those keep it.
     useSorted_ = cfg_.fused == -1 && tileListDev_ != nullptr && doUpscale_ && doSharpen_ && !cfg_.use_nis &&
                  in.format == OVRFSR_FORMAT_RGBA8_UNORM && IntermediateFormat() == OVRFSR_FORMAT_RGBA8_UNORM;
