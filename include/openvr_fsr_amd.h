@@ -47,11 +47,16 @@ typedef enum ovrfsr_eye { OVRFSR_EYE_LEFT = 0, OVRFSR_EYE_RIGHT = 1 } ovrfsr_eye
 /* Pixel formats of the linear device buffers that stand in for ID3D11Texture2D.
  * RGBA8_UNORM is what the reference allocates for its outputs (DetermineOutputFormat,
  * PostProcessor.cpp:63-74); RGBA16F is the packed-half I/O of BASELINE config C5; RGBA32F exists
- * so that parity can be measured on un-quantised results. */
+ * so that parity can be measured on un-quantised results.  RGB10A2_UNORM (DXGI_FORMAT_R10G10B10A2_UNORM
+ * bit layout: R 0-9, G 10-19, B 20-29, A 30-31) is the other format DetermineOutputFormat returns: a
+ * 10-bit submission keeps 10-bit intermediate and output textures.  It is accepted as input with a
+ * RGB10A2 (or, for parity measurements, RGBA32F) output, two-kernel pipeline only (cfg.fused = 1 is
+ * rejected for it). */
 typedef enum ovrfsr_format {
     OVRFSR_FORMAT_RGBA8_UNORM = 0,
     OVRFSR_FORMAT_RGBA16F = 1,
-    OVRFSR_FORMAT_RGBA32F = 2
+    OVRFSR_FORMAT_RGBA32F = 2,
+    OVRFSR_FORMAT_RGB10A2_UNORM = 3
 } ovrfsr_format;
 
 /* Arithmetic the kernels run in.  The reference only ever compiles the fp32 bodies

@@ -31,7 +31,7 @@ size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 {
     if (prec != PREC_FP32_STRICT && easu_fast_pitch(cellsW) != 0)
         return (size_t)easu_fast_pitch(cellsW) * cellsH * (16 + 16 + 4);
-    const bool wide = (prec == PREC_FP32_STRICT) || (in_fmt == FMT_RGBA32F);
+    const bool wide = (prec == PREC_FP32_STRICT) || (in_fmt == FMT_RGBA32F) || (in_fmt == FMT_RGB10A2);
     const size_t ncell = (size_t)cellsW * cellsH;
     const size_t col = (ncell * (wide ? 16 : 8) + 15) & ~(size_t)15;
     return col + ncell * 16 + ncell * 4;
@@ -56,7 +56,7 @@ static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t
 }
 
 #define OVRFSR_DISPATCH_FMT(FN, ...)                                                                     \
-    switch (in_fmt * 3 + out_fmt) {                                                                      \
+    switch (in_fmt < 3 && out_fmt < 3 ? in_fmt * 3 + out_fmt : -1) {                                                                      \
     case 0: return FN<FMT_RGBA8, FMT_RGBA8>(__VA_ARGS__);                                                \
     case 1: return FN<FMT_RGBA8, FMT_RGBA16F>(__VA_ARGS__);                                              \
     case 2: return FN<FMT_RGBA8, FMT_RGBA32F>(__VA_ARGS__);                                              \
@@ -66,8 +66,29 @@ static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t
     case 6: return FN<FMT_RGBA32F, FMT_RGBA8>(__VA_ARGS__);                                              \
     case 7: return FN<FMT_RGBA32F, FMT_RGBA16F>(__VA_ARGS__);                                            \
     case 8: return FN<FMT_RGBA32F, FMT_RGBA32F>(__VA_ARGS__);                                            \
-    default: return hipErrorInvalidValue;                                                                \
-    }
+    default: break;                                                                                      \
+    }                                                                                                    \
+    /* R10G10B10A2: only what the reference's 10-bit path needs (10-bit in -> 10-bit out, PostProcessor.cpp:63-74) plus a \
+       float destination for un-quantised parity checks */                                               \
+    if (in_fmt == FMT_RGB10A2 && out_fmt == FMT_RGB10A2) return FN<FMT_RGB10A2, FMT_RGB10A2>(__VA_ARGS__); \
+    if (in_fmt == FMT_RGB10A2 && out_fmt == FMT_RGBA32F) return FN<FMT_RGB10A2, FMT_RGBA32F>(__VA_ARGS__); \
+    return hipErrorInvalidValue;
+
+// the same without the 10-bit pairs: kernels that are not built for R10G10B10A2 (fused, LDS-staged outside)
+#define OVRFSR_DISPATCH_FMT3(FN, ...)                                                                     \
+    switch (in_fmt < 3 && out_fmt < 3 ? in_fmt * 3 + out_fmt : -1) {                                                                      \
+    case 0: return FN<FMT_RGBA8, FMT_RGBA8>(__VA_ARGS__);                                                \
+    case 1: return FN<FMT_RGBA8, FMT_RGBA16F>(__VA_ARGS__);                                              \
+    case 2: return FN<FMT_RGBA8, FMT_RGBA32F>(__VA_ARGS__);                                              \
+    case 3: return FN<FMT_RGBA16F, FMT_RGBA8>(__VA_ARGS__);                                              \
+    case 4: return FN<FMT_RGBA16F, FMT_RGBA16F>(__VA_ARGS__);                                            \
+    case 5: return FN<FMT_RGBA16F, FMT_RGBA32F>(__VA_ARGS__);                                            \
+    case 6: return FN<FMT_RGBA32F, FMT_RGBA8>(__VA_ARGS__);                                              \
+    case 7: return FN<FMT_RGBA32F, FMT_RGBA16F>(__VA_ARGS__);                                            \
+    case 8: return FN<FMT_RGBA32F, FMT_RGBA32F>(__VA_ARGS__);                                            \
+    default: break;                                                                                      \
+    }                                                                                                    \
+    return hipErrorInvalidValue;
 
 // LDS of the fused kernel: EASU planes + 34x34 float4 intermediate
 size_t fused_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
@@ -117,7 +138,7 @@ hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const Fu
     if (!strict && easu_fast_pitch(a.cellsW) == 0) return hipErrorInvalidValue;
     const dim3 grid(a.tileList ? nTiles : a.tilesX * a.tilesY, 1, batch);
     const size_t lds = fused_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH);
-    OVRFSR_DISPATCH_FMT(fused_go, mid_fmt, strict, a, grid, lds, s)
+    OVRFSR_DISPATCH_FMT3(fused_go, mid_fmt, strict, a, grid, lds, s)
 }
 
 template <int I, int O>
@@ -169,9 +190,9 @@ hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt
     if (!a.tileList || !a.bilX || !a.bilY || nTiles == 0 || !outside_staged_ok(a.v, in_fmt)) return hipErrorInvalidValue;
     if (a.lds_cols < 2 || a.lds_cols > 36 || a.lds_rows < 2 || a.lds_rows > 34) return hipErrorInvalidValue;
     const dim3 grid(nTiles, 1, batch);
-    if (tileH == 24) { OVRFSR_DISPATCH_FMT(outside_staged_go24, mid_fmt, a, grid, s) }
+    if (tileH == 24) { OVRFSR_DISPATCH_FMT3(outside_staged_go24, mid_fmt, a, grid, s) }
     if (tileH != 32) return hipErrorInvalidValue;
-    OVRFSR_DISPATCH_FMT(outside_staged_go32, mid_fmt, a, grid, s)
+    OVRFSR_DISPATCH_FMT3(outside_staged_go32, mid_fmt, a, grid, s)
 }
 
 // nTiles blocks, each resolving tile a.tileList[block]: tiles entirely outside the radius (product build only).

@@ -49,7 +49,7 @@ static hipError_t sharpen_go(bool strict, const NisArgs &a, dim3 grid, hipStream
 }
 
 #define OVRFSR_DISPATCH_FMT(FN, ...)                                                                     \
-    switch (in_fmt * 3 + out_fmt) {                                                                      \
+    switch (in_fmt < 3 && out_fmt < 3 ? in_fmt * 3 + out_fmt : -1) {                                                                      \
     case 0: return FN<FMT_RGBA8, FMT_RGBA8>(__VA_ARGS__);                                                \
     case 1: return FN<FMT_RGBA8, FMT_RGBA16F>(__VA_ARGS__);                                              \
     case 2: return FN<FMT_RGBA8, FMT_RGBA32F>(__VA_ARGS__);                                              \
@@ -59,8 +59,13 @@ static hipError_t sharpen_go(bool strict, const NisArgs &a, dim3 grid, hipStream
     case 6: return FN<FMT_RGBA32F, FMT_RGBA8>(__VA_ARGS__);                                              \
     case 7: return FN<FMT_RGBA32F, FMT_RGBA16F>(__VA_ARGS__);                                            \
     case 8: return FN<FMT_RGBA32F, FMT_RGBA32F>(__VA_ARGS__);                                            \
-    default: return hipErrorInvalidValue;                                                                \
-    }
+    default: break;                                                                                      \
+    }                                                                                                    \
+    /* R10G10B10A2: only what the reference's 10-bit path needs (10-bit in -> 10-bit out, PostProcessor.cpp:63-74) plus a \
+       float destination for un-quantised parity checks */                                               \
+    if (in_fmt == FMT_RGB10A2 && out_fmt == FMT_RGB10A2) return FN<FMT_RGB10A2, FMT_RGB10A2>(__VA_ARGS__); \
+    if (in_fmt == FMT_RGB10A2 && out_fmt == FMT_RGBA32F) return FN<FMT_RGB10A2, FMT_RGBA32F>(__VA_ARGS__); \
+    return hipErrorInvalidValue;
 
 template <int I, int O>
 static hipError_t nis_outside_go(const NisArgs &a, dim3 grid, hipStream_t s)

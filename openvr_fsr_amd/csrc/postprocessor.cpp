@@ -13,7 +13,7 @@ namespace ovrfsr {
 
 static uint32_t texel_bytes(uint32_t fmt)
 {
-    return fmt == OVRFSR_FORMAT_RGBA8_UNORM ? 4u : fmt == OVRFSR_FORMAT_RGBA16F ? 8u : 16u;
+    return fmt == OVRFSR_FORMAT_RGBA8_UNORM || fmt == OVRFSR_FORMAT_RGB10A2_UNORM ? 4u : fmt == OVRFSR_FORMAT_RGBA16F ? 8u : 16u;
 }
 
 // hipSetDevice for the duration of a call, then back to whatever the caller had selected
@@ -113,7 +113,7 @@ int PostProcessor::SetConfig(const ovrfsr_config &cfg)
 int PostProcessor::CheckImage(const ovrfsr_image *img, const char *name)
 {
     if (!img || !img->data) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": null image");
-    if (img->format > OVRFSR_FORMAT_RGBA32F) return Fail(OVRFSR_ERR_UNSUPPORTED, std::string(name) + ": unknown format");
+    if (img->format > OVRFSR_FORMAT_RGB10A2_UNORM) return Fail(OVRFSR_ERR_UNSUPPORTED, std::string(name) + ": unknown format");
     const uint32_t tb = texel_bytes(img->format);
     if (img->width == 0 || img->height == 0 || img->width > 16384 || img->height > 16384)
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": bad size");
@@ -144,8 +144,10 @@ uint32_t PostProcessor::IntermediateFormat() const
     // the reference's upscaledTexture has the output format: R8G8B8A8_UNORM (PostProcessor.cpp:348 via :63-74).
     // Half-float pipelines (BASELINE C5) keep a half-float intermediate; quantize_intermediate=0 keeps fp32.
     if (!cfg_.quantize_intermediate) return OVRFSR_FORMAT_RGBA32F;
+    // a 10-bit submission keeps 10-bit resources (DetermineOutputFormat, :63-74)
     return inputFormat_ == OVRFSR_FORMAT_RGBA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM
-         : inputFormat_ == OVRFSR_FORMAT_RGBA16F ? OVRFSR_FORMAT_RGBA16F : OVRFSR_FORMAT_RGBA32F;
+         : inputFormat_ == OVRFSR_FORMAT_RGBA16F ? OVRFSR_FORMAT_RGBA16F
+         : inputFormat_ == OVRFSR_FORMAT_RGB10A2_UNORM ? OVRFSR_FORMAT_RGB10A2_UNORM : OVRFSR_FORMAT_RGBA32F;
 }
 
 void PostProcessor::PrepareUpscalingResources()
@@ -291,7 +293,9 @@ int PostProcessor::PrepareResources(const ovrfsr_image &in)
     useFused_ = false;
     // auto: masked product-build pipelines run fused + mask-sorted (most of their pixels are plain bilinear copies, and tiles outside the
     // radius need no intermediate at all); unmasked ones stay two-pass (VALU-bound, the ring recompute costs 9 %)
-    const bool autoFused = cfg_.fused == -1 && tileListDev_ != nullptr && fusedCellsW_ <= 40 &&
+    const bool tenBit = in.format == OVRFSR_FORMAT_RGB10A2_UNORM; // two-kernel pipeline only (header)
+    if (tenBit && cfg_.fused == 1) return Fail(OVRFSR_ERR_UNSUPPORTED, "the fused kernel is not built for RGB10A2 images");
+    const bool autoFused = !tenBit && cfg_.fused == -1 && tileListDev_ != nullptr && fusedCellsW_ <= 40 &&
                            fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) <= 160 * 1024;
     // auto on a masked product-build EASU+RCAS pipeline: the two-pass kernels on the tiles touching the radius, tiles
     // outside written in final form (ApplySorted); cfg.fused = 1 keeps the single fused kernel on those tiles
@@ -685,6 +689,10 @@ int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, cons
 int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                                     const ovrfsr_image &out, size_t outStride, hipStream_t stream)
 {
+    // R10G10B10A2 exists for the reference's 10-bit path: 10-bit in -> 10-bit out (or float, to measure parity)
+    const bool inTen = in.format == OVRFSR_FORMAT_RGB10A2_UNORM, outTen = out.format == OVRFSR_FORMAT_RGB10A2_UNORM;
+    if ((outTen && !inTen) || (inTen && !outTen && out.format != OVRFSR_FORMAT_RGBA32F))
+        return Fail(OVRFSR_ERR_UNSUPPORTED, "RGB10A2 images pair with an RGB10A2 (or RGBA32F) destination only");
     if (cfg_.debug_mode && evStart_) (void)hipEventRecord(evStart_, stream);
     int rc = OVRFSR_OK;
     if (useSorted_) {

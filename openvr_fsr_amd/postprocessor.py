@@ -12,7 +12,12 @@ _FMT_TORCH = {K.FORMAT_RGBA8: torch.uint8, K.FORMAT_RGBA16F: torch.float16, K.FO
 
 
 def image_of(t):
-    """[H, W, 4] device tensor -> ovrfsr_image (no copy)."""
+    """[H, W, 4] device tensor -> ovrfsr_image (no copy).  A [H, W] int32 tensor is an R10G10B10A2_UNORM image (one packed
+    dword per texel: R bits 0-9, G 10-19, B 20-29, A 30-31)."""
+    if t.dim() == 2 and t.dtype == torch.int32 and t.is_cuda:
+        if t.stride(1) != 1:
+            raise ValueError("texels must be contiguous")
+        return K.Image(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * 4, K.FORMAT_RGB10A2)
     if t.dim() != 3 or t.shape[2] != 4 or not t.is_cuda:
         raise ValueError("expected a [H, W, 4] tensor on the GPU")
     if t.stride(2) != 1 or t.stride(1) != 4:
@@ -68,7 +73,8 @@ class PostProcessor:
         img = image_of(tex)
         if out is None and out_dtype is not None:
             ow, oh = self.output_size(tex.shape[1], tex.shape[0])
-            out = torch.empty((oh, ow, 4), dtype=out_dtype, device=tex.device)
+            shape = (oh, ow) if out_dtype == torch.int32 else (oh, ow, 4)  # int32 = packed R10G10B10A2
+            out = torch.empty(shape, dtype=out_dtype, device=tex.device)
         oimg = image_of(out) if out is not None else K.Image()
         b = C.byref(bounds) if bounds is not None else None
         self._check(self._lib.ovrfsr_apply(self._ctx, int(eye), C.byref(img), b, C.byref(oimg), self._stream()))
@@ -95,13 +101,17 @@ class PostProcessor:
 
 def _wrap(img, device):
     """View ctx-owned device memory as a torch tensor without copying (via __cuda_array_interface__)."""
-    dt = _FMT_TORCH[img.format]
-    es = torch.empty((), dtype=dt).element_size()
 
     class _Holder:
         pass
 
     h = _Holder()
+    if img.format == K.FORMAT_RGB10A2:   # one packed dword per texel
+        h.__cuda_array_interface__ = {"shape": (img.height, img.width), "typestr": "<i4", "strides": (img.pitch_bytes, 4),
+                                      "data": (img.data, False), "version": 2}
+        return torch.as_tensor(h, device=device)
+    dt = _FMT_TORCH[img.format]
+    es = torch.empty((), dtype=dt).element_size()
     typestr = {torch.uint8: "|u1", torch.float16: "<f2", torch.float32: "<f4"}[dt]
     h.__cuda_array_interface__ = {"shape": (img.height, img.width, 4), "typestr": typestr,
                                   "strides": (img.pitch_bytes, 4 * es, es), "data": (img.data, False), "version": 2}

@@ -1,0 +1,143 @@
+"""R10G10B10A2_UNORM images -- the other texture format the reference allocates (DetermineOutputFormat,
+PostProcessor.cpp:63-74: a 10-bit submission keeps 10-bit intermediate and output textures) -- through the HIP path
+against the oracle: the float filters of the oracle composed with the UNORM10 decode / encode stated here."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+STRICT, FP32 = 2, 0
+
+
+def pack10(f):
+    """float [H,W,4] -> packed dwords [H,W] (UNORM10 x3 + UNORM2): floor(sat(x)*scale + 0.5), fp32, unfused"""
+    f = np.clip(np.asarray(f, np.float32), 0, 1)
+    q = np.floor(f[..., :3] * np.float32(1023) + np.float32(0.5)).astype(np.uint32)
+    a = np.floor(f[..., 3] * np.float32(3) + np.float32(0.5)).astype(np.uint32)
+    return (q[..., 0] | (q[..., 1] << 10) | (q[..., 2] << 20) | (a << 30)).view(np.int32)
+
+
+def unpack10(p):
+    v = np.ascontiguousarray(p).view(np.uint32)
+    out = np.empty(v.shape + (4,), np.float32)
+    for c in range(3):
+        out[..., c] = ((v >> (10 * c)) & 1023).astype(np.float32) / np.float32(1023)
+    out[..., 3] = (v >> 30).astype(np.float32) / np.float32(3)
+    return out
+
+
+def img10(w, h, seed):
+    rng = np.random.default_rng(seed)
+    base = synth.structured_u8(w, h, seed).astype(np.float32) / 255.0
+    base[..., :3] = np.clip(base[..., :3] + rng.uniform(-0.002, 0.002, (h, w, 3)).astype(np.float32), 0, 1)   # use all 10 bits
+    base[..., 3] = 1.0
+    return pack10(base)
+
+
+def oracle_fsr10(p, ow, oh, sharp, radius=2.0, proj=(0.5,) * 4, eye=0, debug=0, stages=3):
+    ih, iw = p.shape
+    centre, rad = O.mask_constants(ow, oh, radius, proj, True, eye)
+    x = unpack10(p)
+    if stages & 1:
+        x = unpack10(pack10(O.easu(x, ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)))     # 10-bit intermediate texture
+    if stages & 2:
+        x = O.rcas(x, O.rcas_con(sharp, debug), centre, rad)
+    return x
+
+
+def run10(p, ow, oh, out_dtype, eye=0, **kw):
+    import torch
+    import openvr_fsr_amd as A
+    cfg = dict(fsr_enabled=1, out_width=ow, out_height=oh, radius=2.0)
+    cfg.update(kw)
+    pp = A.PostProcessor(**cfg)
+    out = pp.apply(eye, torch.from_numpy(p).cuda(), out_dtype=out_dtype)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy()
+    pp.close()
+    return res
+
+
+@pytest.mark.parametrize("iw,ih,ow,oh", [(96, 80, 128, 107), (150, 120, 200, 160), (61, 47, 80, 63)])
+@pytest.mark.parametrize("radius,debug", [(2.0, 0), (0.5, 1)])
+def test_fsr_rgb10a2_strict_bit_exact(gpu, iw, ih, ow, oh, radius, debug):
+    import torch
+    p = img10(iw, ih, 3)
+    proj = (0.45, 0.5, 0.55, 0.5)
+    want = oracle_fsr10(p, ow, oh, 0.8, radius, proj, 1, debug)
+    got = run10(p, ow, oh, torch.int32, eye=1, precision=STRICT, sharpness=0.8, radius=radius, proj_centre=proj, debug_mode=debug)
+    assert np.array_equal(got.view(np.uint32), pack10(want).view(np.uint32))
+    gotf = run10(p, ow, oh, torch.float32, eye=1, precision=STRICT, sharpness=0.8, radius=radius, proj_centre=proj, debug_mode=debug)
+    assert np.array_equal(gotf.view(np.uint32), want.view(np.uint32))
+    # EASU alone (stage_mask 1) writes the 10-bit texture directly
+    wante = oracle_fsr10(p, ow, oh, 0.8, radius, proj, 1, debug, stages=1)
+    gote = run10(p, ow, oh, torch.int32, eye=1, precision=STRICT, sharpness=0.8, radius=radius, proj_centre=proj, debug_mode=debug, stage_mask=1)
+    assert np.array_equal(gote.view(np.uint32), pack10(wante).view(np.uint32))
+
+
+@pytest.mark.parametrize("radius", [2.0, 0.5])
+def test_fsr_rgb10a2_product_tolerance(gpu, radius):
+    import torch
+    iw, ih, ow, oh = 330, 250, 440, 333
+    p = img10(iw, ih, 9)
+    want = unpack10(pack10(oracle_fsr10(p, ow, oh, 0.9, radius)))
+    got = unpack10(run10(p, ow, oh, torch.int32, precision=FP32, sharpness=0.9, radius=radius))
+    d = np.abs(got - want)[..., :3] * 1023.0
+    # 1 LSB flips of the 10-bit intermediate, amplified <= 4x by RCAS (+1): same reasoning as the UNORM8 bound
+    assert d.max() <= 5.01 and (d > 0.5).mean() <= 4e-3, (float(d.max()), float((d > 0.5).mean()))
+    assert np.array_equal(got[..., 3], want[..., 3])
+
+
+def test_fsr_rgb10a2_rejections(gpu):
+    import torch
+    import openvr_fsr_amd as A
+    p = img10(60, 50, 1)
+    with pytest.raises(A.OvrFsrError):
+        run10(p, 80, 67, torch.uint8)                       # 10-bit in -> 8-bit out is not a pair the reference forms
+    with pytest.raises(A.OvrFsrError):
+        run10(p, 80, 67, torch.int32, fused=1)              # two-kernel pipeline only
+    pp = A.PostProcessor(fsr_enabled=1, out_width=80, out_height=67)
+    with pytest.raises(A.OvrFsrError):
+        pp.apply(0, torch.from_numpy(synth.random_u8(60, 50, 1)).cuda(), out_dtype=torch.int32)   # 8-bit in -> 10-bit out
+    pp.close()
+
+
+def test_nis_rgb10a2_strict_bit_exact(gpu):
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 150, 120, 200, 160
+    p = img10(iw, ih, 4)
+    cs, cu = A.nis_coefs()
+    ok, cfg = A.nis_scaler_config(0.6, iw, ih, ow, oh)
+    assert ok
+    for radius in (2.0, 0.5):
+        centre, rad = O.mask_constants(ow, oh, radius)
+        want = O.nis_upscale(unpack10(p), ow, oh, O.nis_block(cfg, centre, rad, 0), cs, cu)
+        got = run10(p, ow, oh, torch.int32, precision=STRICT, use_nis=1, sharpness=0.6, radius=radius)
+        assert np.array_equal(got.view(np.uint32), pack10(want).view(np.uint32)), radius
+        gotp = unpack10(run10(p, ow, oh, torch.int32, precision=FP32, use_nis=1, sharpness=0.6, radius=radius))
+        assert (np.abs(gotp - unpack10(pack10(want)))[..., :3] * 1023 <= 1.01).mean() >= 0.99
+
+
+def test_rgb10a2_ctx_owned_output_and_ppm(gpu, tmp_path):
+    import ctypes as C
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 96, 80, 128, 107
+    p = img10(iw, ih, 5)
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.7, radius=2.0, precision=STRICT)
+    out = pp.apply(0, torch.from_numpy(p).cuda())            # ctx-owned output keeps the 10-bit format (PostProcessor.cpp:63-74)
+    assert out.dtype == torch.int32 and tuple(out.shape) == (oh, ow)
+    want = oracle_fsr10(p, ow, oh, 0.7)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), pack10(want).view(np.uint32))
+    from openvr_fsr_amd.postprocessor import image_of
+    path = str(tmp_path / "ten.ppm")
+    assert A.library().ovrfsr_save_ppm(C.byref(image_of(out)), path.encode(), None) == 0
+    data = open(path, "rb").read()
+    hdr = b"P6\n%d %d\n255\n" % (ow, oh)
+    assert data.startswith(hdr) and len(data) == len(hdr) + ow * oh * 3
+    rgb = np.frombuffer(data[len(hdr):], np.uint8).reshape(oh, ow, 3)
+    assert np.abs(rgb.astype(np.float32) / 255.0 - unpack10(pack10(want))[..., :3]).max() <= 0.5 / 255 + 1e-6
+    pp.close()
