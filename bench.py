@@ -152,6 +152,22 @@ def usable_cores():
     return n
 
 
+def copy_ceiling_gbps(dev):
+    """What a plain device copy reaches on this chip right now (read + write bytes / time): the practical HBM ceiling
+    next to the 8 TB/s vendor peak (SURVEY.md 8d asks for both)."""
+    n = 1 << 29
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    for _ in range(3):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        b.copy_(a)
+    torch.cuda.synchronize(dev)
+    return 2.0 * n * 10 / (time.perf_counter() - t0) / 1e9
+
+
 def cpu_baseline(inW, inH, outW, outH, sharpness):
     """The oracle (C restatement, OpenMP) on stereo pairs of the same workload, one thread per usable core, for a
     bounded sample: pairs are processed until ~8 s of wall time have passed (at least one, at most eight)."""
@@ -166,7 +182,10 @@ def cpu_baseline(inW, inH, outW, outH, sharpness):
             O.fsr_pipeline_u8(im, outW, outH, sharpness=sharpness, nthreads=cores)
         pairs += 1
     dt = time.perf_counter() - t0
-    return {"value": round(pairs / dt, 4), "unit": "eye-pairs/s", "cores": cores, "kind": "port",
+    t1 = time.perf_counter()   # and one eye on a single thread (report single-thread too)
+    O.fsr_pipeline_u8(imgs[0], outW, outH, sharpness=sharpness, nthreads=1)
+    single = 0.5 / (time.perf_counter() - t1)
+    return {"value": round(pairs / dt, 4), "unit": "eye-pairs/s", "cores": cores, "kind": "port", "single_thread_value": round(single, 4),
             "sample": "%d stereo pair(s) %dx%d->%dx%d RGBA8, EASU+RCAS (UNORM8 intermediate), oracle/liboracle.so with %d OpenMP "
                       "threads (usable cores of this container), %.2f s wall = %.1f core-seconds"
                       % (pairs, inW, inH, outW, outH, cores, dt, dt * cores)}
@@ -255,6 +274,7 @@ def main():
             pe.close()
             easu_bytes = bpp * (inW * inH + outW * outH) * n_img
         ach = easu_bytes / (ms_easu * 1e-3) / 1e9
+        copy_gbps = copy_ceiling_gbps(dev)
         rgba8 = dtype == torch.uint8
         if sharpen_only:
             kname = "nis_sharpen_kernel" if use_nis else "rcas_direct_kernel"
@@ -267,6 +287,7 @@ def main():
         roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, kname, n_img),
                 "launch_ms": round(ms_easu, 4), "algorithmic_bytes_per_launch": easu_bytes,
+                "copy_ceiling": round(copy_gbps, 1), "frac_of_copy": round(ach / copy_gbps, 4),
                 "pipeline_ms_per_step_events": round(ms_step, 4),
                 "pipeline_achieved_GBps": round(algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9, 1),
                 "note": "the kernel is VALU-issue-bound on this chip (see DESIGN.md); frac is reported against the HBM roof the contract names"}
