@@ -51,12 +51,16 @@ typedef enum ovrfsr_eye { OVRFSR_EYE_LEFT = 0, OVRFSR_EYE_RIGHT = 1 } ovrfsr_eye
  * bit layout: R 0-9, G 10-19, B 20-29, A 30-31) is the other format DetermineOutputFormat returns: a
  * 10-bit submission keeps 10-bit intermediate and output textures.  It is accepted as input with a
  * RGB10A2 (or, for parity measurements, RGBA32F) output, two-kernel pipeline only (cfg.fused = 1 is
- * rejected for it). */
+ * rejected for it).  BGRA8_UNORM is input-only: the B8G8R8A8 submissions the reference views through a
+ * typed SRV (TranslateTypelessFormats / MakeSrgbFormatsTypeless, PostProcessor.cpp:30-61) while its own
+ * textures stay R8G8B8A8; here the channels are re-ordered by a copy kernel in front of the pipeline and
+ * everything after it is the RGBA8 path. */
 typedef enum ovrfsr_format {
     OVRFSR_FORMAT_RGBA8_UNORM = 0,
     OVRFSR_FORMAT_RGBA16F = 1,
     OVRFSR_FORMAT_RGBA32F = 2,
-    OVRFSR_FORMAT_RGB10A2_UNORM = 3
+    OVRFSR_FORMAT_RGB10A2_UNORM = 3,
+    OVRFSR_FORMAT_BGRA8_UNORM = 4
 } ovrfsr_format;
 
 /* Arithmetic the kernels run in.  The reference only ever compiles the fp32 bodies

@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-FORMAT_RGBA8, FORMAT_RGBA16F, FORMAT_RGBA32F, FORMAT_RGB10A2 = 0, 1, 2, 3
+FORMAT_RGBA8, FORMAT_RGBA16F, FORMAT_RGBA32F, FORMAT_RGB10A2, FORMAT_BGRA8 = 0, 1, 2, 3, 4
 PRECISION_FP32, PRECISION_FP16, PRECISION_FP32_STRICT = 0, 1, 2
 EYE_LEFT, EYE_RIGHT = 0, 1
 

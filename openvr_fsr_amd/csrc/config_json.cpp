@@ -127,9 +127,10 @@ OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_conf
 // Binary PPM (P6) of a device image; RGBA16F/32F/RGB10A2 are converted like a UNORM8 store.  Synchronises `stream`.
 OVRFSR_API int ovrfsr_save_ppm(const ovrfsr_image *img, const char *path, void *stream)
 {
-    if (!img || !img->data || !path || img->format > OVRFSR_FORMAT_RGB10A2_UNORM) return OVRFSR_ERR_INVALID_ARGUMENT;
+    if (!img || !img->data || !path || img->format > OVRFSR_FORMAT_BGRA8_UNORM) return OVRFSR_ERR_INVALID_ARGUMENT;
     const bool ten = img->format == OVRFSR_FORMAT_RGB10A2_UNORM;
-    const size_t tb = img->format == OVRFSR_FORMAT_RGBA8_UNORM || ten ? 4 : img->format == OVRFSR_FORMAT_RGBA16F ? 8 : 16;
+    const bool bgra = img->format == OVRFSR_FORMAT_BGRA8_UNORM;
+    const size_t tb = img->format == OVRFSR_FORMAT_RGBA8_UNORM || ten || bgra ? 4 : img->format == OVRFSR_FORMAT_RGBA16F ? 8 : 16;
     std::vector<unsigned char> host((size_t)img->pitch_bytes * img->height);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemcpyAsync(host.data(), img->data, host.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return OVRFSR_ERR_HIP;
@@ -144,7 +145,7 @@ OVRFSR_API int ovrfsr_save_ppm(const ovrfsr_image *img, const char *path, void *
         for (uint32_t x = 0; x < img->width; ++x)
             for (int c = 0; c < 3; ++c) {
                 if (ten) { uint32_t v; std::memcpy(&v, src + x * 4, 4); row[x * 3 + c] = q((float)((v >> (10 * c)) & 1023u) / 1023.0f); }
-                else if (tb == 4) row[x * 3 + c] = src[x * 4 + c];
+                else if (tb == 4) row[x * 3 + c] = src[x * 4 + (bgra ? 2 - c : c)];
                 else if (tb == 16) { float v; std::memcpy(&v, src + x * 16 + c * 4, 4); row[x * 3 + c] = q(v); }
                 else { _Float16 h; std::memcpy(&h, src + x * 8 + c * 2, 2); row[x * 3 + c] = q((float)h); }
             }

@@ -209,6 +209,26 @@ hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuA
     OVRFSR_DISPATCH_FMT(easu_outside_go, mid_fmt, a, grid, s)
 }
 
+// B8G8R8A8 -> R8G8B8A8 into a tightly packed buffer (dst pitch = 4*w, image stride = 4*w*h): a byte shuffle, 16 texels
+// per thread row segment; the pipeline behind it is the RGBA8 one.
+__global__ __launch_bounds__(256) void bgra_to_rgba_kernel(const uint8_t *__restrict__ src, uint32_t srcPitch, uint64_t srcStride,
+                                                            uint8_t *__restrict__ dst, uint32_t w, uint32_t h)
+{
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+    if (x >= w) return;
+    const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)img * srcStride + (size_t)y * srcPitch + (size_t)x * 4);
+    // byte order in memory B,G,R,A -> R,G,B,A: swap bytes 0 and 2
+    const uint32_t o = (v & 0xff00ff00u) | ((v >> 16) & 0xffu) | ((v & 0xffu) << 16);
+    *reinterpret_cast<uint32_t *>(dst + ((size_t)img * h + y) * (size_t)w * 4 + (size_t)x * 4) = o;
+}
+
+hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t srcStride, uint8_t *dst, uint32_t w, uint32_t h,
+                               uint32_t batch, hipStream_t s)
+{
+    hipLaunchKernelGGL(bgra_to_rgba_kernel, dim3((w + 255) / 256, h, batch), dim3(256), 0, s, src, srcPitch, srcStride, dst, w, h);
+    return hipGetLastError();
+}
+
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;

@@ -14,6 +14,8 @@ hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uin
 int nis_pitch(int cellsW);
 size_t nis_scaler_lds_bytes(int cellsW, int cellsH);
 hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s, uint32_t nGroups = 0);
+hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t srcStride, uint8_t *dst, uint32_t w, uint32_t h,
+                              uint32_t batch, hipStream_t s);
 bool outside_staged_ok(const BatchView &v, int in_fmt);
 hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt, const OutsideArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s);
 hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_t nGroups, uint32_t batch, hipStream_t s);

@@ -13,7 +13,8 @@ namespace ovrfsr {
 
 static uint32_t texel_bytes(uint32_t fmt)
 {
-    return fmt == OVRFSR_FORMAT_RGBA8_UNORM || fmt == OVRFSR_FORMAT_RGB10A2_UNORM ? 4u : fmt == OVRFSR_FORMAT_RGBA16F ? 8u : 16u;
+    return fmt == OVRFSR_FORMAT_RGBA8_UNORM || fmt == OVRFSR_FORMAT_RGB10A2_UNORM || fmt == OVRFSR_FORMAT_BGRA8_UNORM ? 4u
+         : fmt == OVRFSR_FORMAT_RGBA16F ? 8u : 16u;
 }
 
 // hipSetDevice for the duration of a call, then back to whatever the caller had selected
@@ -85,6 +86,8 @@ void PostProcessor::Reset()
     DeviceGuard guard(device_); // resources live on the ctx's device, whatever the caller has selected
     enabled_ = true;
     initialized_ = false;
+    if (swizzled_) (void)hipFree(swizzled_);
+    swizzled_ = nullptr; swizzledBytes_ = 0;
     if (upscaled_) (void)hipFree(upscaled_);
     if (sharpened_) (void)hipFree(sharpened_);
     if (nisCoefDev_) (void)hipFree(nisCoefDev_);
@@ -113,7 +116,7 @@ int PostProcessor::SetConfig(const ovrfsr_config &cfg)
 int PostProcessor::CheckImage(const ovrfsr_image *img, const char *name)
 {
     if (!img || !img->data) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": null image");
-    if (img->format > OVRFSR_FORMAT_RGB10A2_UNORM) return Fail(OVRFSR_ERR_UNSUPPORTED, std::string(name) + ": unknown format");
+    if (img->format > OVRFSR_FORMAT_BGRA8_UNORM) return Fail(OVRFSR_ERR_UNSUPPORTED, std::string(name) + ": unknown format");
     const uint32_t tb = texel_bytes(img->format);
     if (img->width == 0 || img->height == 0 || img->width > 16384 || img->height > 16384)
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": bad size");
@@ -145,7 +148,7 @@ uint32_t PostProcessor::IntermediateFormat() const
     // Half-float pipelines (BASELINE C5) keep a half-float intermediate; quantize_intermediate=0 keeps fp32.
     if (!cfg_.quantize_intermediate) return OVRFSR_FORMAT_RGBA32F;
     // a 10-bit submission keeps 10-bit resources (DetermineOutputFormat, :63-74)
-    return inputFormat_ == OVRFSR_FORMAT_RGBA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM
+    return inputFormat_ == OVRFSR_FORMAT_RGBA8_UNORM || inputFormat_ == OVRFSR_FORMAT_BGRA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM
          : inputFormat_ == OVRFSR_FORMAT_RGBA16F ? OVRFSR_FORMAT_RGBA16F
          : inputFormat_ == OVRFSR_FORMAT_RGB10A2_UNORM ? OVRFSR_FORMAT_RGB10A2_UNORM : OVRFSR_FORMAT_RGBA32F;
 }
@@ -192,11 +195,13 @@ void PostProcessor::PrepareSharpeningResources()
     rcasCon_[3] = cfg_.debug_mode ? 1u : 0u; // :430
 }
 
-int PostProcessor::PrepareResources(const ovrfsr_image &in)
+int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
 {
-    inputWidth_ = in.width;
-    inputHeight_ = in.height;
-    inputFormat_ = in.format;
+    inputWidth_ = submitted.width;
+    inputHeight_ = submitted.height;
+    inputFormat_ = submitted.format;
+    ovrfsr_image in = submitted; // what the kernels will see: a BGRA8 submission is re-ordered to RGBA8 first (ApplyPostProcess)
+    if (in.format == OVRFSR_FORMAT_BGRA8_UNORM) in.format = OVRFSR_FORMAT_RGBA8_UNORM;
     uint32_t ow = 0, oh = 0;
     if (ovrfsr_output_size(&cfg_, in.width, in.height, &ow, &oh) != OVRFSR_OK || ow == 0 || oh == 0)
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "output size is zero");
@@ -689,6 +694,20 @@ int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, cons
 int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                                     const ovrfsr_image &out, size_t outStride, hipStream_t stream)
 {
+    if (out.format == OVRFSR_FORMAT_BGRA8_UNORM) return Fail(OVRFSR_ERR_UNSUPPORTED, "BGRA8 is an input-only format");
+    if (in.format == OVRFSR_FORMAT_BGRA8_UNORM) {
+        // the reference reads B8G8R8A8 submissions through a typed view and writes R8G8B8A8 (PostProcessor.cpp:30-61,63-74):
+        // re-order the channels once, then run the RGBA8 pipeline on the copy
+        const size_t tight = (size_t)in.width * in.height * 4;
+        int rcs = EnsureBuffer(&swizzled_, &swizzledBytes_, tight * n);
+        if (rcs != OVRFSR_OK) return rcs;
+        hipError_t e = launch_bgra_to_rgba(static_cast<const uint8_t *>(in.data), in.pitch_bytes, inStride, static_cast<uint8_t *>(swizzled_),
+                                           in.width, in.height, n, stream);
+        if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("BGRA8 re-order launch: ") + hipGetErrorString(e));
+        ovrfsr_image rgba = in;
+        rgba.data = swizzled_; rgba.format = OVRFSR_FORMAT_RGBA8_UNORM; rgba.pitch_bytes = in.width * 4;
+        return ApplyPostProcess(n, firstEye, alternate, rgba, tight, out, outStride, stream);
+    }
     // R10G10B10A2 exists for the reference's 10-bit path: 10-bit in -> 10-bit out (or float, to measure parity)
     const bool inTen = in.format == OVRFSR_FORMAT_RGB10A2_UNORM, outTen = out.format == OVRFSR_FORMAT_RGB10A2_UNORM;
     if ((outTen && !inTen) || (inTen && !outTen && out.format != OVRFSR_FORMAT_RGBA32F))
@@ -754,7 +773,7 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
         dst = *out;
     } else {
         dst.width = outputWidth_; dst.height = outputHeight_;
-        dst.format = in->format == OVRFSR_FORMAT_RGBA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM : in->format; // DetermineOutputFormat (:63-74)
+        dst.format = in->format == OVRFSR_FORMAT_BGRA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM : in->format; // DetermineOutputFormat (:63-74)
         dst.pitch_bytes = dst.width * texel_bytes(dst.format);
         rc = EnsureBuffer(&sharpened_, &sharpenedBytes_, (size_t)dst.pitch_bytes * dst.height);
         if (rc != OVRFSR_OK) return rc;

@@ -85,6 +85,8 @@ private:
     int nisCellsW_ = 0, nisCellsH_ = 0;
 
     // ctx-owned device buffers: upscaledTexture / sharpenedTexture, PostProcessor.h:43-45,58-59
+    void *swizzled_ = nullptr;          // RGBA8 copy of a BGRA8 submission (tight pitch), see ApplyPostProcess
+    size_t swizzledBytes_ = 0;
     void *upscaled_ = nullptr;
     size_t upscaledBytes_ = 0;
     void *sharpened_ = nullptr;

@@ -11,8 +11,9 @@ _TORCH_FMT = {torch.uint8: (K.FORMAT_RGBA8, 4), torch.float16: (K.FORMAT_RGBA16F
 _FMT_TORCH = {K.FORMAT_RGBA8: torch.uint8, K.FORMAT_RGBA16F: torch.float16, K.FORMAT_RGBA32F: torch.float32}
 
 
-def image_of(t):
-    """[H, W, 4] device tensor -> ovrfsr_image (no copy).  A [H, W] int32 tensor is an R10G10B10A2_UNORM image (one packed
+def image_of(t, fmt=None):
+    """[H, W, 4] device tensor -> ovrfsr_image (no copy); ``fmt`` overrides the format implied by the dtype (e.g.
+    K.FORMAT_BGRA8 for a uint8 tensor whose channel order is B,G,R,A).  A [H, W] int32 tensor is an R10G10B10A2_UNORM image (one packed
     dword per texel: R bits 0-9, G 10-19, B 20-29, A 30-31)."""
     if t.dim() == 2 and t.dtype == torch.int32 and t.is_cuda:
         if t.stride(1) != 1:
@@ -22,8 +23,8 @@ def image_of(t):
         raise ValueError("expected a [H, W, 4] tensor on the GPU")
     if t.stride(2) != 1 or t.stride(1) != 4:
         raise ValueError("texels must be contiguous RGBA")
-    fmt, tb = _TORCH_FMT[t.dtype]
-    return K.Image(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * t.element_size(), fmt)
+    dfmt, tb = _TORCH_FMT[t.dtype]
+    return K.Image(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * t.element_size(), dfmt if fmt is None else fmt)
 
 
 class PostProcessor:
@@ -67,10 +68,10 @@ class PostProcessor:
     def output_size(self, inW, inH):
         return K.output_size(self.cfg, inW, inH)
 
-    def apply(self, eye, tex, bounds=None, out=None, out_dtype=None):
+    def apply(self, eye, tex, bounds=None, out=None, out_dtype=None, in_format=None):
         """PostProcessor::Apply(eye, texture, bounds).  Returns the tensor the compositor should receive.
         With ``out=None`` and ``out_dtype=None`` the ctx-owned output is wrapped (valid until the next apply)."""
-        img = image_of(tex)
+        img = image_of(tex, in_format)
         if out is None and out_dtype is not None:
             ow, oh = self.output_size(tex.shape[1], tex.shape[0])
             shape = (oh, ow) if out_dtype == torch.int32 else (oh, ow, 4)  # int32 = packed R10G10B10A2
@@ -84,10 +85,10 @@ class PostProcessor:
             return tex  # pass-through (fsr disabled)
         return _wrap(oimg, tex.device)
 
-    def apply_batch(self, texs, outs, first_eye=K.EYE_LEFT, alternate_eyes=True):
+    def apply_batch(self, texs, outs, first_eye=K.EYE_LEFT, alternate_eyes=True, in_format=None):
         """texs: [N, H, W, 4], outs: [N, outH, outW, 4] (image i = eye first_eye ^ (i & alternate))."""
         n = texs.shape[0]
-        i0, o0 = image_of(texs[0]), image_of(outs[0])
+        i0, o0 = image_of(texs[0], in_format), image_of(outs[0])
         self._check(self._lib.ovrfsr_apply_batch(self._ctx, n, int(first_eye), int(bool(alternate_eyes)), C.byref(i0),
                                                  texs.stride(0) * texs.element_size(), C.byref(o0),
                                                  outs.stride(0) * outs.element_size(), self._stream()))

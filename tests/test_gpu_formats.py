@@ -141,3 +141,37 @@ def test_rgb10a2_ctx_owned_output_and_ppm(gpu, tmp_path):
     rgb = np.frombuffer(data[len(hdr):], np.uint8).reshape(oh, ow, 3)
     assert np.abs(rgb.astype(np.float32) / 255.0 - unpack10(pack10(want))[..., :3]).max() <= 0.5 / 255 + 1e-6
     pp.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# B8G8R8A8 submissions (input only): the reference views them through a typed SRV and writes R8G8B8A8
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nis,radius,prec", [(0, 2.0, STRICT), (0, 0.5, FP32), (1, 2.0, STRICT), (1, 0.5, FP32)])
+def test_bgra8_input_equals_rgba8(gpu, nis, radius, prec):
+    """A BGRA8 image is re-ordered by a copy kernel and then takes the RGBA8 pipeline: bit-identical to submitting the
+    RGBA8 image, for single applies (ctx-owned output) and strided batches, FSR and NIS (whose luma weights are not symmetric
+    in R and B), every build."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 150, 120, 200, 160
+    imgs = np.stack([synth.structured_u8(iw, ih, 40 + i) for i in range(3)])
+    bgra = np.ascontiguousarray(imgs[..., [2, 1, 0, 3]])
+    kw = dict(fsr_enabled=1, use_nis=nis, out_width=ow, out_height=oh, sharpness=0.8, radius=radius, precision=prec, debug_mode=1)
+    pp = A.PostProcessor(**kw)
+    want = torch.empty((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    pp.apply_batch(torch.from_numpy(imgs).cuda(), want, first_eye=1, alternate_eyes=True)
+    pad = torch.zeros((3, ih, iw + 5, 4), dtype=torch.uint8, device="cuda")     # row pitch wider than the image
+    pad[:, :, :iw] = torch.from_numpy(bgra).cuda()
+    got = torch.zeros_like(want)
+    pp.apply_batch(pad[:, :, :iw], got, first_eye=1, alternate_eyes=True, in_format=A.FORMAT_BGRA8)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    one = pp.apply(1, torch.from_numpy(bgra[0]).cuda(), in_format=A.FORMAT_BGRA8)   # ctx-owned output: R8G8B8A8
+    assert one.dtype == torch.uint8 and torch.equal(one, want[0])
+    with pytest.raises(A.OvrFsrError):
+        from openvr_fsr_amd.postprocessor import image_of
+        import ctypes as C
+        o = image_of(got[0], A.FORMAT_BGRA8)
+        i = image_of(torch.from_numpy(imgs[0]).cuda())
+        pp._check(pp._lib.ovrfsr_apply(pp._ctx, 0, C.byref(i), None, C.byref(o), None))   # BGRA8 as a destination
+    pp.close()
