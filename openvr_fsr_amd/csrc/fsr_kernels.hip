@@ -26,11 +26,13 @@ namespace ovrfsr {
 
 // LDS row pitch (cells) of the product-build EASU kernel; 0 = footprint too wide, use the generic kernel
 int easu_fast_pitch(int cellsW) { return cellsW <= 32 ? 32 : cellsW <= 40 ? 40 : 0; }
+// the EASU-only kernel also has a 28-cell pitch: exactly the footprint of a 32-pixel tile at scale 3/4
+static int easu_kernel_pitch(int cellsW) { return cellsW <= 28 ? 28 : easu_fast_pitch(cellsW); }
 
 size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 {
     if (prec != PREC_FP32_STRICT && easu_fast_pitch(cellsW) != 0)
-        return (size_t)easu_fast_pitch(cellsW) * cellsH * (16 + 16 + 4);
+        return (size_t)easu_fast_pitch(cellsW) * cellsH * (16 + 16 + 4); // sized for pitch 32/40 (the fused kernel's); 28 fits inside
     const bool wide = (prec == PREC_FP32_STRICT) || (in_fmt == FMT_RGBA32F) || (in_fmt == FMT_RGB10A2);
     const size_t ncell = (size_t)cellsW * cellsH;
     const size_t col = (ncell * (wide ? 16 : 8) + 15) & ~(size_t)15;
@@ -40,8 +42,9 @@ size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 template <int I, int O>
 static hipError_t easu_go(bool strict, const EasuArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    const int pitch = easu_fast_pitch(a.cellsW);
+    const int pitch = easu_kernel_pitch(a.cellsW);
     if (strict) hipLaunchKernelGGL((ovrfsr_strict::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 28) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 28>), grid, dim3(kThreads), (size_t)28 * a.cellsH * 36, s, a);
     else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, a);
     else if (pitch == 40) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
