@@ -1,31 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- stereo eye-pairs/sec of the EASU+RCAS hot path at 1683x1869 -> 2244x2492 (BASELINE.json
-config C2), achieved fraction of the HBM roofline for the dominant kernel, and the CPU oracle timed
-beside it.
+config C2), achieved fraction of the HBM roofline for the dominant kernel (with the roof that actually binds
+it, VALU issue, measured beside it), and the CPU oracle timed in the same run.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU; batches shard, no data-path collective)
 
-A "step" = one pass of the hot path (PostProcessor::Apply for both eyes of every pair) over one
-batch of `--pairs` synthetic stereo pairs that are already resident in HBM.  Weak scaling: every
-rank owns its own batch.
+A "step" = one pass of the hot path (PostProcessor::Apply for both eyes of every pair) over one batch of
+`--pairs` synthetic stereo pairs per GPU that are already resident in HBM.  Batches shard embarrassingly
+(SURVEY.md 8e): every GPU owns its own sub-batch, its own ctx and its own stream; nothing is exchanged, no RCCL.
+
+Two ways to run N GPUs, same shards, same JSON line:
+  * direct      `python bench.py --gpus N`: ONE process, N ctxs (ovrfsr_create(dev_i)), one host thread and one
+                stream per device, per-device HIP-event timing, host max-join.
+  * torchrun    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`: one rank per GPU; the ranks
+                only meet at the timing barrier and the max-reduce of one scalar, over gloo (host sockets).
+Documented scale configuration (BASELINE C4: 1024 pairs over 8 GPUs = 128 resident pairs per GPU):
+  python bench.py --gpus 8 --workload C4 --pairs 128 --steps 10 --warmup 3
 """
 import argparse
-import ctypes as C
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
+import numpy as np  # noqa: E402,F401
 import torch  # noqa: E402
 
-CLOCK_RAMP_S = 0.3      # untimed sustained load before the warm-up steps (see main)
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable by a float4 copy
+CLOCK_RAMP_S = 0.3      # untimed sustained load before the warm-up steps (see run_job)
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~5500 reached by a plain device copy
+# VALU issue peak: 1024 SIMD-32 units x 32 lanes x 2.4 GHz = lane-instructions per second if every wave64
+# instruction issued in 2 cycles (MI355X_MICROARCH.md: v_fma_f32 = 2 cycles per wave64 on a SIMD-32)
+VALU_PEAK_LANE_INSTR = 1024 * 32 * 2.4e9
 
 WORKLOADS = {
     # name: (inW, inH, outW, outH, in/out dtype, radius, use_nis)   -- BASELINE.json configs
@@ -38,8 +52,12 @@ WORKLOADS = {
     "C2s": (2244, 2492, 2244, 2492, torch.uint8, 2.0, 0),    # renderScale 1: RCAS only (PostProcessor.cpp:586-594)
     "C3s": (2244, 2492, 2244, 2492, torch.uint8, 2.0, 1),    # renderScale 1 with useNis: NVSharpen only
 }
+SHARPNESS = 0.9
 
 
+# ------------------------------------------------------------------------------------------------
+# synthetic inputs, generated on the device that consumes them
+# ------------------------------------------------------------------------------------------------
 def random_batch(n_img, w, h, dtype, device, base_seed):
     """Uniform-random texels (second distribution of SURVEY.md 8d: no smooth regions, worst case for edge analysis)."""
     g = torch.Generator(device=device)
@@ -84,14 +102,125 @@ def synth_batch(n_img, w, h, dtype, device, base_seed):
     return out
 
 
-def shard_seed(pairs_per_gpu, rank):
-    """Seed of the first eye image of `rank`'s shard: image g (global index) has seed 0x5EED0000 + g, i.e.
-    0x5EED0000 + 2*pair + eye; rank r owns global pairs [r*P, (r+1)*P)."""
-    return 0x5EED0000 + 2 * pairs_per_gpu * rank
+def shard_seed(pairs_per_gpu, shard):
+    """Seed of the first eye image of shard `shard`: image g (global index) has seed 0x5EED0000 + g, i.e.
+    0x5EED0000 + 2*pair + eye; shard s owns global pairs [s*P, (s+1)*P)."""
+    return 0x5EED0000 + 2 * pairs_per_gpu * shard
+
+
+# ------------------------------------------------------------------------------------------------
+# shards: one per GPU.  A shard owns its inputs, outputs, ctx; step() is asynchronous on its device.
+# ------------------------------------------------------------------------------------------------
+class GpuShard:
+    """The sub-batch of one GPU: `pairs` stereo pairs generated on that GPU, a ctx created on it
+    (ovrfsr_create(device)), outputs resident there.  Nothing of a shard ever leaves its device."""
+
+    def __init__(self, device_index, shard_index, args):
+        import openvr_fsr_amd as A
+        self.A = A
+        self.device_index, self.shard_index = device_index, shard_index
+        self.dev = torch.device("cuda", device_index)
+        inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
+        prec = {"fp32": A.PRECISION_FP32, "strict": A.PRECISION_FP32_STRICT}[args.precision]
+        self.n_img = 2 * args.pairs
+        with torch.cuda.device(self.dev):
+            gen = synth_batch if args.content == "structured" else random_batch
+            self.texs = gen(self.n_img, inW, inH, dtype, self.dev, shard_seed(args.pairs, shard_index))
+            self.outs = torch.empty((self.n_img, outH, outW, 4), dtype=dtype, device=self.dev)
+            self.cfg_kw = dict(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=SHARPNESS, radius=radius,
+                               precision=prec, fused=args.fused, quantize_intermediate=1)
+            self.pp = A.PostProcessor(device=device_index, **self.cfg_kw)
+            self.ev0, self.ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def bind(self):
+        torch.cuda.set_device(self.dev)     # per host thread
+
+    def step(self):
+        self.pp.apply_batch(self.texs, self.outs, first_eye=self.A.EYE_LEFT, alternate_eyes=True)
+
+    def sync(self):
+        torch.cuda.synchronize(self.dev)
+
+    def mark_start(self):
+        self.ev0.record(torch.cuda.current_stream(self.dev))
+
+    def mark_end(self):
+        self.ev1.record(torch.cuda.current_stream(self.dev))
+
+    def device_ms(self):
+        self.ev1.synchronize()
+        return self.ev0.elapsed_time(self.ev1)
+
+    def close(self):
+        self.pp.close()
+
+
+def build_shards(n_local, first_shard, make):
+    """The launcher's partition: shard i of this process = global shard first_shard + i on local device i."""
+    return [make(i, first_shard + i) for i in range(n_local)]
+
+
+def run_local(shards, steps, warmup, ramp_s=0.0, cross_barrier=None):
+    """Run `warmup` untimed + EXACTLY `steps` timed steps on every local shard concurrently (one host thread per
+    device; one shard runs inline).  The timed region is bracketed by sync + barrier on both sides; returns
+    (wall seconds of the slowest shard, [device milliseconds per shard from HIP events on the launch stream])."""
+    n = len(shards)
+    gate = threading.Barrier(n)
+    t_start, t_end, dev_ms, errors = [0.0] * n, [0.0] * n, [0.0] * n, []
+
+    def all_ranks():
+        if cross_barrier is not None:
+            cross_barrier()
+
+    def work(i):
+        try:
+            s = shards[i]
+            s.bind()
+            # clock ramp: a cold MI355X takes ~50 ms of sustained load to reach its steady clocks; run the step for a
+            # fixed wall time first so that short --warmup values read the same steady state as long ones.  Untimed.
+            t = time.perf_counter()
+            while time.perf_counter() - t < ramp_s:
+                s.step()
+                s.sync()
+            for _ in range(warmup):
+                s.step()
+            s.sync()
+            gate.wait()
+            if i == 0:
+                all_ranks()
+            gate.wait()
+            t_start[i] = time.perf_counter()
+            s.mark_start()
+            for _ in range(steps):
+                s.step()
+            s.mark_end()
+            s.sync()
+            gate.wait()
+            if i == 0:
+                all_ranks()
+            gate.wait()
+            t_end[i] = time.perf_counter()
+            dev_ms[i] = s.device_ms()
+        except BaseException as e:  # noqa: BLE001 -- reported by the caller; never leave the other threads at the gate
+            errors.append(e)
+            gate.abort()
+
+    if n == 1:
+        work(0)
+    else:
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    return max(t_end) - min(t_start), dev_ms
 
 
 def timed_region(step, steps, barrier):
-    """EXACTLY `steps` calls of step() bracketed by barrier()+sync on both sides; returns local wall seconds."""
+    """EXACTLY `steps` calls of step() bracketed by barrier()+sync on both sides; returns local wall seconds.
+    (The single-shard form of run_local, kept for the torchrun path's CPU test.)"""
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -100,27 +229,20 @@ def timed_region(step, steps, barrier):
     return time.perf_counter() - t0
 
 
-def max_over_ranks(dt, world, device):
+def max_over_ranks(dt, world, device=None):
+    """Host-side max-join of one scalar per rank (gloo: the data path has no collective, so the timing join does not
+    need RCCL either)."""
     if world == 1:
         return dt
     import torch.distributed as dist
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def measured_traffic(workload, kernel, n_img):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this workload (tools/profile.sh:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 correction on FETCH_SIZE), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic_per_eye.json")
-    try:
-        per_eye = json.load(open(path))[workload]
-        hit = [v for k, v in per_eye.items() if any(k.endswith("::" + part) for part in kernel.split("+"))]
-        return int(sum(h["hbm_bytes_per_eye"] for h in hit) * n_img) if hit else None
-    except (OSError, KeyError, ValueError):
-        return None
-
-
+# ------------------------------------------------------------------------------------------------
+# roofline helpers
+# ------------------------------------------------------------------------------------------------
 def time_events(fn, iters, stream):
     """Average ms per call of fn() measured with HIP events recorded on `stream`."""
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -168,6 +290,145 @@ def copy_ceiling_gbps(dev):
     return 2.0 * n * 10 / (time.perf_counter() - t0) / 1e9
 
 
+def dominant_kernels(workload):
+    """Kernel name(s) the roofline object is about (substring match on rocprofv3's Kernel_Name)."""
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[workload]
+    rgba8 = dtype == torch.uint8
+    if (inW, inH) == (outW, outH):
+        return ["nis_sharpen_kernel"] if use_nis else ["rcas_direct_kernel"]
+    if use_nis:   # NVScaler (+ the DirectCopy kernel of the groups outside the radius, concurrent)
+        return ["nis_scaler_kernel"] + ((["outside_staged_kernel"] if rgba8 else ["nis_outside_kernel"]) if radius < 2.0 else [])
+    if radius < 2.0:  # tiles touching the radius: EASU+RCAS (RGBA8) or the fused kernel; the rest in final form, concurrent
+        return ["easu_fast_kernel", "rcas_direct_kernel", "outside_staged_kernel"] if rgba8 else ["fused_kernel", "easu_outside_kernel"]
+    return ["easu_fast_kernel"]
+
+
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]]
+PMC_CHILD_PAIRS = 4
+
+
+def pmc_counters(args, timeout_s=240):
+    """HBM traffic and VALU counters of this workload's kernels, measured IN THIS RUN: bench.py re-runs itself (a few
+    steps, `--pmc-child`) under `rocprofv3 --pmc <counters>`, one pass per counter group, counters only (no trace
+    options -- the guide's recipe).  Returns {kernel name: {counter: mean per dispatch}} with images per dispatch, or
+    None if rocprofv3 is not usable here."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    import csv
+    agg = {}
+    for counters in PMC_PASSES:
+        tmp = tempfile.mkdtemp(prefix="ovrfsr_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                                           "--pmc-child", "--workload", args.workload, "--content", args.content, "--precision", args.precision,
+                                           "--fused", str(args.fused), "--pairs", str(PMC_CHILD_PAIRS)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            files = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp) for f in fs if f.endswith("counter_collection.csv")]
+            for fn in files:
+                for r in csv.DictReader(open(fn)):
+                    k = r.get("Kernel_Name", "")
+                    if "ovrfsr" not in k:
+                        continue
+                    m = re.search(r"ovrfsr_\w+::(\w+)", k)
+                    short = m.group(1) if m else k
+                    agg.setdefault(short, {}).setdefault(r.get("Counter_Name"), []).append(float(r.get("Counter_Value", 0)))
+        except (subprocess.SubprocessError, OSError, ValueError):
+            pass   # this pass is lost (counter group not collectable here); the others still count
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    if not agg:
+        return None
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+
+
+def pmc_child(args):
+    """What runs under rocprofv3 --pmc: the same step on a small batch, a few times; prints nothing."""
+    args.pairs = PMC_CHILD_PAIRS
+    s = GpuShard(0, 0, args)
+    s.bind()
+    for _ in range(3):
+        s.step()
+    s.sync()
+    s.close()
+
+
+def profile_traffic(workload, kernels, n_img):
+    """Fallback when counters cannot be read in this run: the committed rocprofv3 PMC summary of this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic_per_eye.json")
+    try:
+        per_eye = json.load(open(path))[workload]
+        hit = [v for k, v in per_eye.items() if any(k.endswith("::" + part) for part in kernels)]
+        return int(sum(h["hbm_bytes_per_eye"] for h in hit) * n_img) if hit else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def roofline(args, shard):
+    """The dominant kernel against the HBM roof the contract names, and against the roof that binds it (VALU issue)."""
+    A = shard.A
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
+    dev, n_img = shard.dev, shard.n_img
+    bpp = shard.texs.element_size() * 4
+    algo_bytes_eye = bpp * (inW * inH + outW * outH)  # pipeline compulsory traffic per eye (SURVEY 8d)
+    stream = torch.cuda.current_stream(dev)
+    iters = max(5, args.steps // 2)
+    ms_step = time_events(shard.step, iters, stream)
+    kernels = dominant_kernels(args.workload)
+    single_pass = len(kernels) > 1 or use_nis or (inW, inH) == (outW, outH)
+    if single_pass:
+        # masked / NIS / sharpen-only: the step IS the kernel (plus its concurrent companions when masked)
+        ms_dom, dom_bytes, out_px = ms_step, algo_bytes_eye * n_img, outW * outH * n_img
+    else:
+        # dominant kernel of the two-pass pipeline: EASU -- launched alone over the same batch
+        kw = dict(shard.cfg_kw, stage_mask=1)
+        pe = A.PostProcessor(cfg=A.Config.default(**kw), device=shard.device_index)
+        ms_dom = time_events(lambda: pe.apply_batch(shard.texs, shard.outs, first_eye=A.EYE_LEFT, alternate_eyes=True), iters, stream)
+        pe.close()
+        dom_bytes, out_px = bpp * (inW * inH + outW * outH) * n_img, outW * outH * n_img
+    ach = dom_bytes / (ms_dom * 1e-3) / 1e9
+    pipe = algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9
+    copy_gbps = copy_ceiling_gbps(dev)
+    roof = {"bound": "hbm", "kernel": "+".join(kernels), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
+            "launch_ms": round(ms_dom, 4), "algorithmic_bytes_per_launch": dom_bytes,
+            "copy_ceiling": round(copy_gbps, 1), "frac_of_copy": round(ach / copy_gbps, 4),
+            "pipeline_ms_per_step_events": round(ms_step, 4), "pipeline_achieved_GBps": round(pipe, 1),
+            "pipeline_frac": round(pipe / HBM_PEAK_GBPS, 4), "binding_roof": "valu_issue", "valu": None}
+    pmc = pmc_counters(args) if args.pmc == "auto" else None
+    if pmc:
+        scale = n_img / (2.0 * PMC_CHILD_PAIRS)   # counters were read on launches of 2*PMC_CHILD_PAIRS images
+        hit = {k: v for k, v in pmc.items() if k in kernels}
+        if hit and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in hit.values()):
+            # WRITE_SIZE + 2 x FETCH_SIZE, KiB per dispatch (gfx950: FETCH_SIZE reports half the bytes of a coalesced read)
+            roof["traffic"] = int(sum(v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"] for v in hit.values()) * 1024.0 * scale)
+            roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (launches of %d images, scaled to %d)" % (2 * PMC_CHILD_PAIRS, n_img)
+            roof["traffic_per_kernel"] = {k: int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024.0 * scale) for k, v in hit.items()}
+        if hit and all("SQ_INSTS_VALU" in v for v in hit.values()):
+            instr = sum(v["SQ_INSTS_VALU"] for v in hit.values()) * scale          # wave-instructions per launch (step)
+            lane_rate = instr * 64.0 / (ms_dom * 1e-3)
+            busy = None
+            if len(hit) == 1:
+                v = next(iter(hit.values()))
+                if v.get("GRBM_GUI_ACTIVE"):   # SQ_ACTIVE_INST_* tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
+                    busy = round(4.0 * v["SQ_ACTIVE_INST_VALU"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)
+            roof["valu"] = {"instr_per_64px": round(instr / (out_px / 64.0), 1), "lane_instr_per_s": round(lane_rate, 0),
+                            "peak": VALU_PEAK_LANE_INSTR, "frac": round(lane_rate / VALU_PEAK_LANE_INSTR, 4), "valu_busy": busy,
+                            "per_kernel_instr_per_64px": {k: round(v["SQ_INSTS_VALU"] * scale / (out_px / 64.0), 1) for k, v in hit.items()},
+                            "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE pass of this run; "
+                                      "valu_busy = 4*SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs); peak = 1024 SIMD-32 x 32 lanes x 2.4 GHz"}
+    if roof["traffic"] is None:
+        roof["traffic"] = profile_traffic(args.workload, kernels, n_img)
+        if roof["traffic"] is not None:
+            roof["traffic_source"] = "profiles/traffic_per_eye.json (committed rocprofv3 PMC summary; not re-measured in this run)"
+    roof["note"] = ("frac is against the HBM roof the contract names; the kernels are VALU-issue-bound on this chip "
+                    "(valu.valu_busy ~ 1.0), so valu.frac / valu.instr_per_64px are the figures that move with kernel work")
+    return roof
+
+
 def cpu_baseline(inW, inH, outW, outH, sharpness):
     """The oracle (C restatement, OpenMP) on stereo pairs of the same workload, one thread per usable core, for a
     bounded sample: pairs are processed until ~8 s of wall time have passed (at least one, at most eight)."""
@@ -191,130 +452,84 @@ def cpu_baseline(inW, inH, outW, outH, sharpness):
                       % (pairs, inW, inH, outW, outH, cores, dt, dt * cores)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--pairs", type=int, default=16, help="stereo pairs per GPU per step")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "fp16", "strict"])
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "strict"])
     ap.add_argument("--fused", type=int, default=-1)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
+                    help="auto: read HBM-traffic and VALU counters in this run (rocprofv3 --pmc child passes, ~1 min)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--content", default="structured", choices=["structured", "random"],
                     help="synthetic eye content: structured (gradients+edges+noise, default) or uniform random")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def plan(args, env):
+    """(world, rank, local device indices, first shard index): torchrun gives one device per rank; a direct
+    invocation drives all --gpus devices from this process."""
+    world = int(env.get("WORLD_SIZE", "1"))
+    rank = int(env.get("RANK", "0"))
+    if world > 1:
+        return world, rank, [int(env.get("LOCAL_RANK", "0"))], rank
+    return 1, 0, list(range(max(1, args.gpus))), 0
+
+
+def main():
+    args = parse_args()
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
-    torch.cuda.set_device(local_rank)          # before the process group: its collectives must use THIS rank's GPU
-    dev = torch.device("cuda", local_rank)
+    if args.pmc_child:
+        return pmc_child(args)
+    world, rank, devices, first_shard = plan(args, os.environ)
+    assert len(devices) <= torch.cuda.device_count(), "--gpus %d but only %d device(s) visible" % (len(devices), torch.cuda.device_count())
+    cross = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL: only the timing barrier / max-reduce use it
+        dist.init_process_group(backend="gloo")   # host-side barrier + max-join only; the data path has no collective
+        cross = dist.barrier
+    torch.cuda.set_device(devices[0])
+    shards = build_shards(len(devices), first_shard, lambda i, s: GpuShard(devices[i], s, args))
+    n_gpus = world * len(devices)
 
-    import openvr_fsr_amd as A
+    dt_local, dev_ms = run_local(shards, args.steps, args.warmup, CLOCK_RAMP_S, cross)
+    dt = max_over_ranks(dt_local, world)
+
     inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
-    sharpness = 0.9
-    prec = {"fp32": A.PRECISION_FP32, "fp16": A.PRECISION_FP16, "strict": A.PRECISION_FP32_STRICT}[args.precision]
-    n_img = 2 * args.pairs
-    base_seed = shard_seed(args.pairs, rank)
-    texs = (synth_batch if args.content == "structured" else random_batch)(n_img, inW, inH, dtype, dev, base_seed)
-    outs = torch.empty((n_img, outH, outW, 4), dtype=dtype, device=dev)
-    pp = A.PostProcessor(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=sharpness, radius=radius,
-                         precision=prec, fused=args.fused, quantize_intermediate=1, device=local_rank)
-
-    def step():
-        pp.apply_batch(texs, outs, first_eye=A.EYE_LEFT, alternate_eyes=True)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    # clock ramp: a cold MI355X takes ~50 ms of sustained load to reach its steady clocks (20 steps after 3 warm-up
-    # steps read 5 % low); run the step for a fixed wall time first so that short --warmup values measure the same
-    # steady state as long ones.  Untimed, before the W warm-up steps; recorded in the JSON line.
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < CLOCK_RAMP_S:
-        step()
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    dt = max_over_ranks(timed_region(step, args.steps, barrier), world, dev)
-
-    pairs_total = args.pairs * world * args.steps
-    value = pairs_total / dt
-    bpp = texs.element_size() * 4
-    algo_bytes_eye = bpp * (inW * inH + outW * outH)  # pipeline compulsory traffic per eye
-
-    # ---- roofline of the dominant kernel, timed live with HIP events on the launch stream ---------
-    stream = torch.cuda.current_stream(dev)
-    roof = None
+    value = args.pairs * n_gpus * args.steps / dt
+    roof = cpu = None
     if rank == 0:
-        ms_step = time_events(step, max(5, args.steps // 2), stream)
-        masked_fsr = (radius < 2.0) and not use_nis
-        sharpen_only = (inW, inH) == (outW, outH)   # renderScale 1: RCAS / NVSharpen alone
-        if masked_fsr or use_nis or sharpen_only:  # single-pass forms: the step is the kernel (+ its concurrent companion when masked)
-            # masked EASU+RCAS runs as one mask-sorted pipeline (tiles touching the radius: EASU+RCAS or the fused kernel;
-            # the rest written in final form by a concurrent kernel): the step itself is the dominant "kernel"
-            ms_easu = ms_step
-            easu_bytes = algo_bytes_eye * n_img
-        else:
-            # dominant kernel: EASU of the two-pass pipeline (NVScaler for NIS) -- launch it alone over the same batch
-            cfge = A.Config.default(fsr_enabled=1, use_nis=use_nis, out_width=outW, out_height=outH, sharpness=sharpness,
-                                    radius=radius, precision=prec, stage_mask=1)
-            pe = A.PostProcessor(cfg=cfge, device=local_rank)
-            ms_easu = time_events(lambda: pe.apply_batch(texs, outs, first_eye=A.EYE_LEFT, alternate_eyes=True),
-                                  max(5, args.steps // 2), stream)
-            pe.close()
-            easu_bytes = bpp * (inW * inH + outW * outH) * n_img
-        ach = easu_bytes / (ms_easu * 1e-3) / 1e9
-        copy_gbps = copy_ceiling_gbps(dev)
-        rgba8 = dtype == torch.uint8
-        if sharpen_only:
-            kname = "nis_sharpen_kernel" if use_nis else "rcas_direct_kernel"
-        elif use_nis:   # NVScaler (+ the DirectCopy kernel of the groups outside the radius, concurrent)
-            kname = "nis_scaler_kernel" + (("+outside_rgba8_kernel" if rgba8 else "+nis_outside_kernel") if radius < 2.0 else "")
-        elif masked_fsr:  # tiles touching the radius: EASU+RCAS (RGBA8) or the fused kernel; the rest in final form, concurrent
-            kname = "easu_fast_kernel+rcas_direct_kernel+outside_rgba8_kernel" if rgba8 else "fused_kernel+easu_outside_kernel"
-        else:
-            kname = "easu_fast_kernel"
-        roof = {"bound": "hbm", "kernel": kname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": measured_traffic(args.workload, kname, n_img),
-                "launch_ms": round(ms_easu, 4), "algorithmic_bytes_per_launch": easu_bytes,
-                "copy_ceiling": round(copy_gbps, 1), "frac_of_copy": round(ach / copy_gbps, 4),
-                "pipeline_ms_per_step_events": round(ms_step, 4),
-                "pipeline_achieved_GBps": round(algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9, 1),
-                "note": "the kernel is VALU-issue-bound on this chip (see DESIGN.md); frac is reported against the HBM roof the contract names"}
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu and not use_nis and dtype == torch.uint8:  # CPU baseline: N=1 only
-        cpu = cpu_baseline(inW, inH, outW, outH, sharpness)
-
-    if rank == 0:
+        shards[0].bind()
+        roof = roofline(args, shards[0])
+        if n_gpus == 1 and not args.no_cpu and not use_nis and dtype == torch.uint8:  # CPU baseline: N=1 only
+            cpu = cpu_baseline(inW, inH, outW, outH, SHARPNESS)
         line = {
             "metric": "stereo eye-pairs/sec at 1683x1869->2244x2492 (EASU+RCAS)" if args.workload == "C2"
                       else "stereo eye-pairs/sec (%s)" % args.workload,
-            "value": round(value, 2), "unit": "eye-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "eye-pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "fp16": "f16", "strict": "f32"}[args.precision],
-            "data": "synthetic (%s)" % args.content,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (%s)" % args.content,
             "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, %s, sharpness 0.9, radius %.1f"
                                    % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F",
                                       ("NIS NVSharpen" if (inW, inH) == (outW, outH) else "NIS NVScaler") if use_nis else
                                       ("RCAS" if (inW, inH) == (outW, outH) else "EASU+RCAS (UNORM8 intermediate)"), radius),
                        "pairs_per_gpu_per_step": args.pairs, "precision": args.precision, "clock_ramp_s": CLOCK_RAMP_S,
-                       "parallelism": "batch sharded over %d GPU(s), no collective" % world},
+                       "launcher": "torchrun, one rank per GPU, gloo timing barrier" if world > 1
+                                   else "one process, %d device(s), one host thread + stream per device" % len(devices),
+                       "per_device_ms_per_step": [round(m / args.steps, 4) for m in dev_ms],
+                       "parallelism": "batch sharded over %d GPU(s), no collective" % n_gpus},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    pp.close()
+    for s in shards:
+        s.close()
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

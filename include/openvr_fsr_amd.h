@@ -78,7 +78,7 @@ typedef enum ovrfsr_precision {
 /* Stands in for vr::Texture_t{handle,eType,eColorSpace} (headers/openvr.h:177-182) plus the
  * D3D11_TEXTURE2D_DESC the reference queries from the handle (PostProcessor.cpp:137-139). */
 typedef struct ovrfsr_image {
-    void *data;           /* device pointer to texel (0,0); 16-byte aligned                      */
+    void *data;           /* device pointer to texel (0,0); aligned to the texel size (4 / 8 / 16 B)    */
     uint32_t width;       /* texels                                                              */
     uint32_t height;      /* texels                                                              */
     uint32_t pitch_bytes; /* distance between rows; multiple of the texel size; >= width*texel   */
@@ -180,6 +180,13 @@ OVRFSR_API const char *ovrfsr_last_error(const ovrfsr_ctx *ctx);
  * (PostProcessor.cpp:579-628).  Blocks until that work is done.  Only recorded when
  * cfg.debug_mode != 0. */
 OVRFSR_API int ovrfsr_last_gpu_time_ms(ovrfsr_ctx *ctx, float *ms);
+
+/* The reference's debug-mode log line "Average GPU processing time for upscale" (PostProcessor.cpp:605-626): a ring of
+ * 6 timestamp pairs, the oldest read back after every apply, the mean of 500 readings published -- doubled when each eye
+ * has its own texture (one reading = one eye, the figure = one frame).  *ms = the last published mean (0 before the
+ * first), *reports = how many have been published; with OVRFSR_LOG=1 in the environment each one is also printed to
+ * stderr in the reference's wording.  Only recorded when cfg.debug_mode != 0. */
+OVRFSR_API int ovrfsr_average_gpu_time_ms(ovrfsr_ctx *ctx, float *ms, uint32_t *reports);
 
 /* ---- constants-only entry points (known-answer tests; no GPU needed) ------------------------- */
 

@@ -89,6 +89,7 @@ def library():
     L.ovrfsr_last_error.argtypes = [C.c_void_p]
     L.ovrfsr_last_error.restype = C.c_char_p
     L.ovrfsr_last_gpu_time_ms.argtypes = [C.c_void_p, f32p]
+    L.ovrfsr_average_gpu_time_ms.argtypes = [C.c_void_p, f32p, u32p]
     L.ovrfsr_easu_con.argtypes = [u32p] + [C.c_float] * 6
     L.ovrfsr_easu_con.restype = None
     L.ovrfsr_rcas_con.argtypes = [u32p, C.c_float]

@@ -2,6 +2,7 @@
 // No exception crosses this boundary (the reference swallows failures the same way,
 // PostProcessor.cpp:145-152).
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include "postprocessor.hpp"
@@ -13,6 +14,21 @@ struct ovrfsr_ctx {
 
 namespace {
 bool config_ok(const ovrfsr_config *cfg) { return cfg && cfg->struct_size == sizeof(ovrfsr_config); }
+
+// Nothing may unwind through the extern "C" boundary (header: "nothing here throws"): host-side containers of the launch
+// manager can throw std::bad_alloc, which becomes a status like every other failure.
+template <typename F>
+int guarded(F &&f) noexcept
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return OVRFSR_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return OVRFSR_ERR_INVALID_ARGUMENT;
+    }
+}
+constexpr uint32_t kMaxExtent = 16384; // same limit CheckImage puts on caller images
 } // namespace
 
 extern "C" {
@@ -40,18 +56,20 @@ OVRFSR_API int ovrfsr_output_size(const ovrfsr_config *cfg, uint32_t in_w, uint3
 {
     if (!config_ok(cfg) || !out_w || !out_h) return OVRFSR_ERR_INVALID_ARGUMENT;
     if (cfg->out_width != 0 && cfg->out_height != 0) {
+        if (cfg->out_width > kMaxExtent || cfg->out_height > kMaxExtent) return OVRFSR_ERR_INVALID_ARGUMENT;
         *out_w = cfg->out_width;
         *out_h = cfg->out_height;
         return OVRFSR_OK;
     }
-    // uint32 <- float truncation, PostProcessor.cpp:512-518
-    if (cfg->render_scale < 1.f) {
-        *out_w = (uint32_t)(in_w / cfg->render_scale);
-        *out_h = (uint32_t)(in_h / cfg->render_scale);
-    } else {
-        *out_w = (uint32_t)(in_w * cfg->render_scale);
-        *out_h = (uint32_t)(in_h * cfg->render_scale);
-    }
+    // uint32 <- float truncation, PostProcessor.cpp:512-518.  A zero, negative or non-finite scale (a typo in
+    // openvr_mod.cfg) has no defined uint conversion, and a tiny one asks for an unbounded image: both are rejected,
+    // like any size beyond the 16384 texels an image may have here.
+    const float s = cfg->render_scale;
+    if (!std::isfinite(s) || !(s > 0.f)) return OVRFSR_ERR_INVALID_ARGUMENT;
+    const float fw = s < 1.f ? in_w / s : in_w * s, fh = s < 1.f ? in_h / s : in_h * s;
+    if (!(fw < (float)(kMaxExtent + 1)) || !(fh < (float)(kMaxExtent + 1))) return OVRFSR_ERR_INVALID_ARGUMENT;
+    *out_w = (uint32_t)fw;
+    *out_h = (uint32_t)fh;
     return OVRFSR_OK;
 }
 
@@ -64,12 +82,14 @@ OVRFSR_API int ovrfsr_create(int device, const ovrfsr_config *cfg, ovrfsr_ctx **
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return OVRFSR_ERR_NO_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return OVRFSR_ERR_NO_DEVICE; // kernels are gfx950-only
-    ovrfsr_ctx *c = new (std::nothrow) ovrfsr_ctx;
-    if (!c) return OVRFSR_ERR_OUT_OF_MEMORY;
-    c->pp = new (std::nothrow) ovrfsr::PostProcessor(device, *cfg);
-    if (!c->pp) { delete c; return OVRFSR_ERR_OUT_OF_MEMORY; }
-    *out_ctx = c;
-    return OVRFSR_OK;
+    return guarded([&] {
+        ovrfsr_ctx *c = new (std::nothrow) ovrfsr_ctx;
+        if (!c) return (int)OVRFSR_ERR_OUT_OF_MEMORY;
+        c->pp = new (std::nothrow) ovrfsr::PostProcessor(device, *cfg);
+        if (!c->pp) { delete c; return (int)OVRFSR_ERR_OUT_OF_MEMORY; }
+        *out_ctx = c;
+        return (int)OVRFSR_OK;
+    });
 }
 
 OVRFSR_API void ovrfsr_destroy(ovrfsr_ctx *ctx)
@@ -82,7 +102,7 @@ OVRFSR_API void ovrfsr_destroy(ovrfsr_ctx *ctx)
 OVRFSR_API int ovrfsr_set_config(ovrfsr_ctx *ctx, const ovrfsr_config *cfg)
 {
     if (!ctx || !config_ok(cfg)) return OVRFSR_ERR_INVALID_ARGUMENT;
-    return ctx->pp->SetConfig(*cfg);
+    return guarded([&] { return ctx->pp->SetConfig(*cfg); });
 }
 
 OVRFSR_API int ovrfsr_get_config(const ovrfsr_ctx *ctx, ovrfsr_config *cfg)
@@ -95,23 +115,23 @@ OVRFSR_API int ovrfsr_get_config(const ovrfsr_ctx *ctx, ovrfsr_config *cfg)
 OVRFSR_API int ovrfsr_reset(ovrfsr_ctx *ctx)
 {
     if (!ctx) return OVRFSR_ERR_INVALID_ARGUMENT;
-    ctx->pp->Reset();
-    return OVRFSR_OK;
+    return guarded([&] { ctx->pp->Reset(); return (int)OVRFSR_OK; });
 }
 
 OVRFSR_API int ovrfsr_apply(ovrfsr_ctx *ctx, int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds,
                             ovrfsr_image *out, void *stream)
 {
     if (!ctx) return OVRFSR_ERR_INVALID_ARGUMENT;
-    return ctx->pp->Apply(eye, in, bounds, out, static_cast<hipStream_t>(stream));
+    return guarded([&] { return ctx->pp->Apply(eye, in, bounds, out, static_cast<hipStream_t>(stream)); });
 }
 
 OVRFSR_API int ovrfsr_apply_batch(ovrfsr_ctx *ctx, uint32_t n, int first_eye, int alternate_eyes, const ovrfsr_image *in0,
                                   size_t in_stride_bytes, const ovrfsr_image *out0, size_t out_stride_bytes, void *stream)
 {
     if (!ctx) return OVRFSR_ERR_INVALID_ARGUMENT;
-    return ctx->pp->ApplyBatch(n, first_eye, alternate_eyes, in0, in_stride_bytes, out0, out_stride_bytes,
-                               static_cast<hipStream_t>(stream));
+    return guarded([&] {
+        return ctx->pp->ApplyBatch(n, first_eye, alternate_eyes, in0, in_stride_bytes, out0, out_stride_bytes, static_cast<hipStream_t>(stream));
+    });
 }
 
 OVRFSR_API const char *ovrfsr_last_error(const ovrfsr_ctx *ctx) { return ctx ? ctx->pp->LastError() : "null ctx"; }
@@ -119,7 +139,13 @@ OVRFSR_API const char *ovrfsr_last_error(const ovrfsr_ctx *ctx) { return ctx ? c
 OVRFSR_API int ovrfsr_last_gpu_time_ms(ovrfsr_ctx *ctx, float *ms)
 {
     if (!ctx) return OVRFSR_ERR_INVALID_ARGUMENT;
-    return ctx->pp->LastGpuTimeMs(ms);
+    return guarded([&] { return ctx->pp->LastGpuTimeMs(ms); });
+}
+
+OVRFSR_API int ovrfsr_average_gpu_time_ms(ovrfsr_ctx *ctx, float *ms, uint32_t *reports)
+{
+    if (!ctx) return OVRFSR_ERR_INVALID_ARGUMENT;
+    return guarded([&] { return ctx->pp->AverageGpuTimeMs(ms, reports); });
 }
 
 OVRFSR_API void ovrfsr_easu_con(uint32_t con[16], float vw, float vh, float iw, float ih, float ow, float oh)

@@ -105,10 +105,8 @@ float as_float(const std::map<std::string, std::string> &m, const char *k, doubl
 
 extern "C" {
 
-OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_config *cfg)
+static int config_from_json_impl(const char *text, size_t len, ovrfsr_config *cfg)
 {
-    if (!cfg || (!text && len)) return OVRFSR_ERR_INVALID_ARGUMENT;
-    ovrfsr_config_default(cfg);
     Parser ps{text, text + len};
     ps.value("", 0);
     ps.ws();
@@ -124,8 +122,29 @@ OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_conf
     return OVRFSR_OK;
 }
 
+OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_config *cfg)
+{
+    if (!cfg || (!text && len)) return OVRFSR_ERR_INVALID_ARGUMENT;
+    ovrfsr_config_default(cfg);
+    try { // std::map / std::string may throw; nothing unwinds through the C boundary
+        return config_from_json_impl(text, len, cfg);
+    } catch (...) {
+        ovrfsr_config_default(cfg);
+        return OVRFSR_ERR_OUT_OF_MEMORY;
+    }
+}
+
 // Binary PPM (P6) of a device image; RGBA16F/32F/RGB10A2 are converted like a UNORM8 store.  Synchronises `stream`.
+static int save_ppm_impl(const ovrfsr_image *img, const char *path, void *stream);
 OVRFSR_API int ovrfsr_save_ppm(const ovrfsr_image *img, const char *path, void *stream)
+{
+    try {
+        return save_ppm_impl(img, path, stream);
+    } catch (...) {
+        return OVRFSR_ERR_OUT_OF_MEMORY;
+    }
+}
+static int save_ppm_impl(const ovrfsr_image *img, const char *path, void *stream)
 {
     if (!img || !img->data || !path || img->format > OVRFSR_FORMAT_BGRA8_UNORM) return OVRFSR_ERR_INVALID_ARGUMENT;
     const bool ten = img->format == OVRFSR_FORMAT_RGB10A2_UNORM;

@@ -71,8 +71,10 @@ PostProcessor::~PostProcessor()
     if (auxStream_) (void)hipStreamDestroy(auxStream_);
     if (evFork_) (void)hipEventDestroy(evFork_);
     if (evJoin_) (void)hipEventDestroy(evJoin_);
-    if (evStart_) (void)hipEventDestroy(evStart_);
-    if (evEnd_) (void)hipEventDestroy(evEnd_);
+    for (ProfileQuery &q : queries_) {
+        if (q.start) (void)hipEventDestroy(q.start);
+        if (q.end) (void)hipEventDestroy(q.end);
+    }
 }
 
 int PostProcessor::Fail(int status, const std::string &what)
@@ -102,7 +104,9 @@ void PostProcessor::Reset()
     lastSubmittedTexture_ = nullptr;
     outputTexture_ = ovrfsr_image{};
     eyeCount_ = 0;
-    timed_ = false;
+    for (ProfileQuery &q : queries_) q.pending = false;
+    lastQuery_ = -1;
+    // summedGpuTime / countedQueries survive a Reset in the reference (plain members, PostProcessor.h:81-82): kept
 }
 
 int PostProcessor::SetConfig(const ovrfsr_config &cfg)
@@ -204,7 +208,7 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
     if (in.format == OVRFSR_FORMAT_BGRA8_UNORM) in.format = OVRFSR_FORMAT_RGBA8_UNORM;
     uint32_t ow = 0, oh = 0;
     if (ovrfsr_output_size(&cfg_, in.width, in.height, &ow, &oh) != OVRFSR_OK || ow == 0 || oh == 0)
-        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "output size is zero");
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "output size is zero or beyond 16384 texels (render_scale must be finite and > 0)");
     outputWidth_ = ow;
     outputHeight_ = oh;
 
@@ -315,9 +319,10 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
             return Fail(OVRFSR_ERR_UNSUPPORTED, "fused kernel: tile footprint does not fit LDS at this scale");
         useFused_ = true;
     }
-    if (cfg_.debug_mode && !evStart_) {
-        if (hipEventCreate(&evStart_) != hipSuccess || hipEventCreate(&evEnd_) != hipSuccess)
-            return Fail(OVRFSR_ERR_HIP, "hipEventCreate failed");
+    if (cfg_.debug_mode && !queries_[0].start) {
+        for (ProfileQuery &q : queries_)
+            if (hipEventCreate(&q.start) != hipSuccess || hipEventCreate(&q.end) != hipSuccess)
+                return Fail(OVRFSR_ERR_HIP, "hipEventCreate failed");
     }
     initialized_ = true;
     return OVRFSR_OK;
@@ -712,7 +717,8 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
     const bool inTen = in.format == OVRFSR_FORMAT_RGB10A2_UNORM, outTen = out.format == OVRFSR_FORMAT_RGB10A2_UNORM;
     if ((outTen && !inTen) || (inTen && !outTen && out.format != OVRFSR_FORMAT_RGBA32F))
         return Fail(OVRFSR_ERR_UNSUPPORTED, "RGB10A2 images pair with an RGB10A2 (or RGBA32F) destination only");
-    if (cfg_.debug_mode && evStart_) (void)hipEventRecord(evStart_, stream);
+    const bool timing = cfg_.debug_mode && queries_[0].start;
+    if (timing) (void)hipEventRecord(queries_[currentQuery_].start, stream);
     int rc = OVRFSR_OK;
     if (useSorted_) {
         rc = ApplySorted(n, firstEye, alternate, in, inStride, out, outStride, stream);
@@ -734,7 +740,12 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
     } else if (doSharpen_) {
         rc = ApplySharpening(n, firstEye, alternate, in, inStride, out, outStride, stream);
     }
-    if (cfg_.debug_mode && evEnd_) { (void)hipEventRecord(evEnd_, stream); timed_ = true; }
+    if (timing) {
+        (void)hipEventRecord(queries_[currentQuery_].end, stream);
+        queries_[currentQuery_].pending = true;
+        lastQuery_ = currentQuery_;
+        CollectQuery(stream);
+    }
     return rc;
 }
 
@@ -809,6 +820,15 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     if (!cfg_.fsr_enabled) return Fail(OVRFSR_ERR_DISABLED, "fsr_enabled is 0: nothing to launch");
     if (n > 1 && (inStride < (size_t)in0->pitch_bytes * in0->height || outStride < (size_t)out0->pitch_bytes * out0->height))
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "batch stride smaller than one image");
+    if (n > 1 && (inStride % texel_bytes(in0->format) != 0 || outStride % texel_bytes(out0->format) != 0))
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "batch stride is not a multiple of the texel size (images i > 0 would be misaligned)");
+    {
+        // the kernels read neighbours of what other workgroups write: input and output ranges must be disjoint
+        const uintptr_t i0 = reinterpret_cast<uintptr_t>(in0->data), o0 = reinterpret_cast<uintptr_t>(out0->data);
+        const uintptr_t i1 = i0 + (n - 1) * inStride + (size_t)in0->pitch_bytes * in0->height;
+        const uintptr_t o1 = o0 + (n - 1) * outStride + (size_t)out0->pitch_bytes * out0->height;
+        if (i0 < o1 && o0 < i1) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output batches overlap");
+    }
     DeviceGuard guard(device_);
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
     if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || !textureContainsOnlyOneEye_))
@@ -823,13 +843,45 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     return ApplyPostProcess(n, firstEye, alternate, *in0, inStride, *out0, outStride, stream);
 }
 
+// PostProcessor.cpp:608-626: advance the ring and read the slot recorded kQueryCount-1 applies ago
+void PostProcessor::CollectQuery(hipStream_t stream)
+{
+    currentQuery_ = (currentQuery_ + 1) % kQueryCount;
+    ProfileQuery &q = queries_[currentQuery_];
+    if (!q.pending) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return; // no host waits while a graph is captured
+    float ms = 0.0f;
+    if (hipEventSynchronize(q.end) != hipSuccess || hipEventElapsedTime(&ms, q.start, q.end) != hipSuccess) return; // "disjoint": reading dropped
+    q.pending = false;
+    summedGpuTime_ += ms * 1e-3f;
+    if (++countedQueries_ >= 500) {
+        float avgTimeMs = 1000.f / countedQueries_ * summedGpuTime_;
+        if (textureContainsOnlyOneEye_) avgTimeMs *= 2;
+        avgGpuTimeMs_ = avgTimeMs;
+        ++avgReports_;
+        static const bool log = [] { const char *e = std::getenv("OVRFSR_LOG"); return e && e[0] == '1'; }();
+        if (log) std::fprintf(stderr, "Average GPU processing time for upscale: %g ms\n", avgTimeMs);
+        countedQueries_ = 0;
+        summedGpuTime_ = 0.f;
+    }
+}
+
 int PostProcessor::LastGpuTimeMs(float *ms)
 {
     if (!ms) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "ms is null");
-    if (!timed_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "no timed apply (debug_mode off?)");
-    hipError_t e = hipEventSynchronize(evEnd_);
-    if (e == hipSuccess) e = hipEventElapsedTime(ms, evStart_, evEnd_);
+    if (lastQuery_ < 0 || !queries_[lastQuery_].start) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "no timed apply (debug_mode off?)");
+    hipError_t e = hipEventSynchronize(queries_[lastQuery_].end);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, queries_[lastQuery_].start, queries_[lastQuery_].end);
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("event timing: ") + hipGetErrorString(e));
+    return OVRFSR_OK;
+}
+
+int PostProcessor::AverageGpuTimeMs(float *ms, uint32_t *reports)
+{
+    if (!ms || !reports) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "null argument");
+    *ms = avgGpuTimeMs_;
+    *reports = avgReports_;
     return OVRFSR_OK;
 }
 

@@ -33,6 +33,7 @@ public:
     const ovrfsr_config &GetConfig() const { return cfg_; }
     const char *LastError() const { return lastError_.c_str(); }
     int LastGpuTimeMs(float *ms);
+    int AverageGpuTimeMs(float *ms, uint32_t *reports);
 
 private:
     int device_;
@@ -92,9 +93,18 @@ private:
     void *sharpened_ = nullptr;
     size_t sharpenedBytes_ = 0;
 
-    // debug-mode GPU timing, PostProcessor.h:72-82
-    hipEvent_t evStart_ = nullptr, evEnd_ = nullptr;
-    bool timed_ = false;
+    // debug-mode GPU timing, PostProcessor.h:72-82: a ring of kQueryCount timestamp pairs; after every apply the OLDEST
+    // slot is read back (so the wait is normally over already), durations are summed and every 500 readings the mean
+    // is published -- doubled when each eye has its own texture, i.e. "per frame" (PostProcessor.cpp:605-626)
+    static constexpr int kQueryCount = 6;
+    struct ProfileQuery { hipEvent_t start = nullptr, end = nullptr; bool pending = false; };
+    ProfileQuery queries_[kQueryCount];
+    int currentQuery_ = 0, lastQuery_ = -1;
+    float summedGpuTime_ = 0.0f;   // seconds
+    int countedQueries_ = 0;
+    float avgGpuTimeMs_ = 0.0f;
+    uint32_t avgReports_ = 0;
+    void CollectQuery(hipStream_t stream);
 
     int Fail(int status, const std::string &what);
     int CheckImage(const ovrfsr_image *img, const char *name);

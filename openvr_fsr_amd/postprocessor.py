@@ -88,6 +88,8 @@ class PostProcessor:
     def apply_batch(self, texs, outs, first_eye=K.EYE_LEFT, alternate_eyes=True, in_format=None):
         """texs: [N, H, W, 4], outs: [N, outH, outW, 4] (image i = eye first_eye ^ (i & alternate))."""
         n = texs.shape[0]
+        if outs.shape[0] != n:
+            raise ValueError("outs holds %d images for a batch of %d" % (outs.shape[0], n))
         i0, o0 = image_of(texs[0], in_format), image_of(outs[0])
         self._check(self._lib.ovrfsr_apply_batch(self._ctx, n, int(first_eye), int(bool(alternate_eyes)), C.byref(i0),
                                                  texs.stride(0) * texs.element_size(), C.byref(o0),
@@ -98,6 +100,14 @@ class PostProcessor:
         ms = C.c_float()
         self._check(self._lib.ovrfsr_last_gpu_time_ms(self._ctx, C.byref(ms)))
         return ms.value
+
+
+    def average_gpu_time_ms(self):
+        """(last published mean of 500 readings in ms -- per frame when each eye has its own texture --, number published):
+        the reference's "Average GPU processing time for upscale" log line (PostProcessor.cpp:605-626)."""
+        ms, n = C.c_float(), C.c_uint32()
+        self._check(self._lib.ovrfsr_average_gpu_time_ms(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
 
 def _wrap(img, device):

@@ -1,0 +1,79 @@
+"""bench.py's launcher on CPU (the step is mocked): `--gpus N` run directly drives N shards -- one per device, disjoint
+contiguous seed ranges, one host thread each, EXACTLY K timed steps per shard -- and reports the slowest shard; under
+torchrun every rank drives one shard.  (Round 1's bench ignored --gpus when invoked directly.)"""
+import threading
+import time
+
+import bench
+
+
+class MockShard:
+    def __init__(self, device_index, shard_index, delay):
+        self.device_index, self.shard_index, self.delay = device_index, shard_index, delay
+        self.steps, self.thread, self.t0, self.t1 = 0, None, None, None
+        self.seed = bench.shard_seed(16, shard_index)
+
+    def bind(self):
+        self.thread = threading.get_ident()
+
+    def step(self):
+        self.steps += 1
+        time.sleep(self.delay)
+
+    def sync(self):
+        pass
+
+    def mark_start(self):
+        self.t0, self.steps_at_start = time.perf_counter(), self.steps
+
+    def mark_end(self):
+        self.t1 = time.perf_counter()
+
+    def device_ms(self):
+        return (self.t1 - self.t0) * 1e3
+
+
+def test_plan_direct_invocation_uses_all_gpus():
+    args = bench.parse_args(["--gpus", "4"])
+    assert bench.plan(args, {}) == (1, 0, [0, 1, 2, 3], 0)
+    assert bench.plan(bench.parse_args([]), {}) == (1, 0, [0], 0)
+
+
+def test_plan_under_torchrun_is_one_device_per_rank():
+    args = bench.parse_args(["--gpus", "8"])
+    assert bench.plan(args, {"WORLD_SIZE": "8", "RANK": "5", "LOCAL_RANK": "5"}) == (8, 5, [5], 5)
+
+
+def test_direct_launcher_creates_and_times_n_shards():
+    n, steps, warmup = 4, 5, 2
+    shards = bench.build_shards(n, 0, lambda i, s: MockShard(i, s, 0.002 * (i + 1)))
+    assert [s.device_index for s in shards] == [0, 1, 2, 3] and [s.shard_index for s in shards] == [0, 1, 2, 3]
+    # disjoint, contiguous image seeds: shard s owns global pairs [16 s, 16 (s+1))
+    assert [s.seed for s in shards] == [0x5EED0000 + 32 * i for i in range(n)]
+    dt, dev_ms = bench.run_local(shards, steps, warmup)
+    assert all(s.steps == warmup + steps and s.steps_at_start == warmup for s in shards)   # EXACTLY K timed steps each
+    assert len({s.thread for s in shards}) == n                                          # one host thread per device
+    assert len(dev_ms) == n and dev_ms[3] > dev_ms[0]
+    assert dt >= steps * 0.008 and dt >= max(dev_ms) / 1e3 - 1e-3                         # wall time = the slowest shard
+    assert dt < 0.5
+
+
+def test_single_shard_runs_inline_and_calls_the_cross_rank_barrier_on_both_sides():
+    calls = []
+    shards = bench.build_shards(1, 3, lambda i, s: MockShard(i, s, 0.0))
+    assert shards[0].shard_index == 3 and shards[0].seed == 0x5EED0000 + 32 * 3
+    bench.run_local(shards, 3, 1, cross_barrier=lambda: calls.append(shards[0].steps))
+    assert calls == [1, 4] and shards[0].thread == threading.get_ident()
+
+
+def test_a_failing_shard_does_not_hang_the_others():
+    class Bad(MockShard):
+        def step(self):
+            raise RuntimeError("boom")
+    shards = [MockShard(0, 0, 0.0), Bad(1, 1, 0.0)]
+    try:
+        bench.run_local(shards, 2, 1)
+    except (RuntimeError, threading.BrokenBarrierError):
+        pass
+    else:
+        raise AssertionError("expected the failure to propagate")

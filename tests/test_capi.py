@@ -50,6 +50,25 @@ def test_output_size_truncation_rule():
     assert A.output_size(A.Config.default(render_scale=0.5, out_width=123, out_height=45), 10, 10) == (123, 45)
 
 
+@pytest.mark.parametrize("scale", [0.0, -1.0, float("nan"), float("inf"), 1e-6, 1e9])
+def test_output_size_rejects_undefined_and_unbounded_scales(scale):
+    """A zero / negative / non-finite renderScale has no defined uint conversion and a tiny (or huge) one asks for an
+    unbounded image: INVALID_ARGUMENT, nothing written, nothing thrown across the C boundary."""
+    cfg = A.Config.default(render_scale=scale)
+    w, h = C.c_uint32(7), C.c_uint32(7)
+    assert A.library().ovrfsr_output_size(C.byref(cfg), 1683, 1869, C.byref(w), C.byref(h)) == 1
+    assert (w.value, h.value) == (7, 7)
+
+
+def test_output_size_is_capped_at_the_image_limit():
+    w, h = C.c_uint32(), C.c_uint32()
+    cfg = A.Config.default(render_scale=0.5)
+    assert A.library().ovrfsr_output_size(C.byref(cfg), 8192, 8192, C.byref(w), C.byref(h)) == 0 and w.value == 16384
+    assert A.library().ovrfsr_output_size(C.byref(cfg), 8193, 100, C.byref(w), C.byref(h)) == 1
+    cfg = A.Config.default(out_width=16385, out_height=10)
+    assert A.library().ovrfsr_output_size(C.byref(cfg), 10, 10, C.byref(w), C.byref(h)) == 1
+
+
 def test_bad_struct_size_is_rejected():
     cfg = A.Config.default()
     cfg.struct_size = 12

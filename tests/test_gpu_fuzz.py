@@ -184,7 +184,7 @@ def test_nis_masked_product_fuzz(gpu, seed):
     assert np.array_equal(got8[outside], O.float_to_unorm8(want)[outside]), (iw, ih, ow, oh, radius)
     gotf = run_gpu(img8, ow, oh, np.float32, **kw)
     assert np.array_equal(gotf[outside].view(np.uint32), want[outside].view(np.uint32)), (iw, ih, ow, oh, radius)
-    assert np.abs(gotf - want).max() <= 0.05
+    assert np.abs(gotf - want).max() <= 1e-3   # north_star's max-abs (nis_getY is unfused in every build: no edge decision can flip)
 
 
 @pytest.mark.parametrize("iw,ih,ow,oh", [(12288, 6, 16384, 8), (6, 12288, 8, 16384), (16383, 3, 16384, 5), (1, 1, 2, 2), (3, 2, 4, 3)])
@@ -215,7 +215,7 @@ def test_extreme_shapes_nis(gpu, iw, ih, ow, oh):
         got = run_gpu(img8, ow, oh, np.float32, precision=STRICT, use_nis=1, sharpness=0.5, radius=radius)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (radius,)
         gotp = run_gpu(img8, ow, oh, np.float32, precision=FP32, use_nis=1, sharpness=0.5, radius=radius)
-        assert np.abs(gotp - want).max() <= 0.05, (radius,)
+        assert np.abs(gotp - want).max() <= 1e-3, (radius,)
 
 
 @pytest.mark.parametrize("seed", range(8))

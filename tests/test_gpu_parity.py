@@ -99,6 +99,7 @@ def test_masked_pipeline_strict_bit_exact(gpu, radius, proj, eye, debug):
 FLOAT_TOL = 2e-5
 LSB_FRACTION = 1e-3
 RCAS_LSB = 5
+NIS_FLOAT_TOL = 1e-3   # north_star's max-abs; measured values are recorded by tests/test_gpu_parity_report.py
 
 
 @pytest.mark.parametrize("iw,ih,ow,oh,gen", SHAPES)
@@ -206,31 +207,32 @@ def test_nis_sharpen_strict_bit_exact(gpu, w, h, gen, radius, debug):
 @pytest.mark.parametrize("w,h,gen,radius,debug", [(128, 107, synth.structured_u8, 2.0, 0), (83, 83, synth.extremes_u8, 0.6, 1),
                                                    (200, 150, synth.random_u8, 2.0, 0)])
 def test_nis_sharpen_fp32_tolerance(gpu, w, h, gen, radius, debug):
-    """NVSharpen, product build: exact wave-uniform skips of zero-weight directional terms + contraction.  Same statistical
-    bound as NVScaler (hard edge thresholds); UNORM8 outputs 99.9 % within 1 LSB."""
+    """NVSharpen, product build: exact wave-uniform skips of zero-weight directional terms + contraction.  The luma that feeds
+    GetEdgeMap's thresholds is evaluated unfused in every build (nis_getY), so no edge decision can flip: north_star's
+    max-abs 1e-3 on float outputs, <= 1 LSB on UNORM8 outputs."""
     img8 = gen(w, h, 31)
     want = _nis_oracle_sharpen(img8, 0.75, radius, debug=debug)
     got = run_gpu(img8, w, h, np.float32, precision=FP32, use_nis=1, render_scale=1.0, sharpness=0.75, radius=radius, debug_mode=debug)
     err = np.abs(got - want)
-    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (float((err <= 1e-3).mean()), float(err.max()))
+    assert err.max() <= NIS_FLOAT_TOL, float(err.max())
     got8 = run_gpu(img8, w, h, np.uint8, precision=FP32, use_nis=1, render_scale=1.0, sharpness=0.75, radius=radius, debug_mode=debug)
     d = np.abs(got8.astype(np.int16) - O.float_to_unorm8(want).astype(np.int16))
-    assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
+    assert d.max() <= 1, int(d.max())
 
 
 @pytest.mark.parametrize("iw,ih,ow,oh,gen", NIS_SHAPES)
 def test_nis_scaler_fp32_tolerance(gpu, iw, ih, ow, oh, gen):
-    # NIS is full of hard thresholds (GetEdgeMap, phase quantisation): the product build (FMA contraction,
-    # v_rcp) may flip one on a near-tie, so the bound is statistical: 99.9 % of values within 1e-3 (north_star's
-    # tolerance), every value within 0.05, UNORM8 outputs 99.9 % within 1 LSB.
+    # NIS is full of hard thresholds (GetEdgeMap, phase quantisation).  Everything that feeds one -- the luma, the
+    # source positions -- is evaluated unfused in the product build too, so none can flip; what remains is rounding
+    # noise of the contracted filters: north_star's max-abs 1e-3 on float outputs, <= 1 LSB on UNORM8 outputs.
     img8 = gen(iw, ih, 21)
     want = _nis_oracle_upscale(img8, ow, oh, 0.9)
     got = run_gpu(img8, ow, oh, np.float32, precision=FP32, use_nis=1, sharpness=0.9)
     err = np.abs(got - want)
-    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (float((err <= 1e-3).mean()), float(err.max()))
+    assert err.max() <= NIS_FLOAT_TOL, float(err.max())
     got8 = run_gpu(img8, ow, oh, np.uint8, precision=FP32, use_nis=1, sharpness=0.9)
     d = np.abs(got8.astype(np.int16) - O.float_to_unorm8(want).astype(np.int16))
-    assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
+    assert d.max() <= 1, int(d.max())
 
 
 @pytest.mark.parametrize("debug", [0, 1])
@@ -270,7 +272,7 @@ def test_nis_scaler_masked_product_lists(gpu, radius, proj, debug):
     for i in range(4):
         want = _nis_oracle_upscale(imgs[i], ow, oh, 0.6, radius, proj, 1 ^ (i & 1), debug)
         err = np.abs(got[i] - want)
-        assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (i, float((err <= 1e-3).mean()), float(err.max()))
+        assert err.max() <= NIS_FLOAT_TOL, (i, float(err.max()))
     one = run_gpu(imgs[0], ow, oh, np.float32, eye=1, precision=FP32, use_nis=1, sharpness=0.6, radius=radius,
                   proj_centre=proj, debug_mode=debug)
     assert np.array_equal(one, got[0])
@@ -311,7 +313,7 @@ def test_c3_full_size_nis(gpu):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     got = run_gpu(img8, ow, oh, np.float32, eye=1, precision=FP32, use_nis=1, sharpness=0.9)
     err = np.abs(got - want)
-    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 0.05, (float((err <= 1e-3).mean()), float(err.max()))
+    assert err.max() <= NIS_FLOAT_TOL, float(err.max())
 
 
 def test_c2_c3_full_size_shipped_radius(gpu):
@@ -337,7 +339,7 @@ def test_c2_c3_full_size_shipped_radius(gpu):
     outside = _outside_px(ow, oh, centre, rad[1], 32, 24)
     assert np.array_equal(gotn[outside], wantn[outside])
     d = np.abs(gotn.astype(np.int16) - wantn.astype(np.int16))
-    assert (d <= 1).mean() >= 0.999, float((d <= 1).mean())
+    assert d.max() <= 1, int(d.max())
 
 
 def test_c4_c5_shapes_properties(gpu):
@@ -539,6 +541,26 @@ def test_masked_product_paths_agree(gpu, radius, proj, debug, fused):
     one = run_gpu(imgs[0], ow, oh, np.uint8, eye=1, precision=FP32, sharpness=0.8, radius=radius, proj_centre=proj,
                   debug_mode=debug, fused=fused)
     assert np.array_equal(one, got[0])
+
+
+@pytest.mark.parametrize("fused", [-1, 0])
+@pytest.mark.parametrize("dt", [np.uint8, np.float16])
+def test_masked_minification_product(gpu, fused, dt):
+    """Explicit output size that minifies by 1.2x with the default radius: the tile footprint is wider than the
+    fixed-pitch product kernels (40 cells), so the runtime-pitch kernel serves the mask-sorted launch and must take its
+    tiles from the list (round 1 bug: it ignored the list and left most inside tiles unwritten)."""
+    iw, ih, ow, oh = 360, 300, 300, 250
+    img8 = synth.structured_u8(iw, ih, 17)
+    img = img8 if dt == np.uint8 else (img8.astype(np.float32) / 255.0).astype(np.float16)
+    want = run_gpu(img, ow, oh, dt, precision=STRICT, sharpness=0.8, radius=0.5, fused=0)
+    got = run_gpu(img, ow, oh, dt, precision=FP32, sharpness=0.8, radius=0.5, fused=fused)
+    if dt == np.uint8:
+        assert np.array_equal(want, O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.8, radius=0.5))
+        mx, frac = lsb_stats(got, want)
+        assert mx <= RCAS_LSB and frac <= 2 * LSB_FRACTION, (mx, frac)
+    else:
+        d = np.abs(got.astype(np.float32) - want.astype(np.float32))
+        assert d.max() <= 4e-3 and (d > 1e-3).mean() <= 1e-4, (float(d.max()), float((d > 1e-3).mean()))
 
 
 @pytest.mark.parametrize("dtype,radius,nis", [(np.uint8, 2.0, 0), (np.uint8, 0.5, 0), (np.float16, 0.5, 0), (np.uint8, 0.5, 1)])

@@ -1,0 +1,152 @@
+"""Measured parity numbers at BASELINE.json's FULL sizes, every config x {strict, product} build, written down.
+
+Each case runs the HIP path through the C ABI and the CPU oracle on the same seeded eye image and records
+  max_abs   largest |difference| on float outputs (unit domain)
+  max_lsb   largest byte difference on UNORM8 outputs
+  n_diff    how many channel values differ at all, of n_total
+into gpurun_out/parity_r02.json (merged back from the GPU box; the copy under profiles/ is the committed record).
+The asserts are the stated tolerances:
+  strict build   bit-exact everywhere (n_diff == 0)
+  product build  float outputs max-abs <= 1e-3 (north_star), measured ~1e-5;
+                 UNORM8 outputs of ONE pass <= 1 LSB;
+                 UNORM8 outputs of EASU -> UNORM8 -> RCAS: the 8-bit intermediate differs from the oracle's in a few
+                 bytes per million (rounding ties of the product build's re-associated sum), and RCAS amplifies such a
+                 1-LSB flip by up to 1/(1-4*0.1875) = 4 (+1 for the final rounding): <= 5 LSB, on <= 1e-4 of the bytes.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import synth
+from tests.util import run_gpu
+
+pytestmark = pytest.mark.gpu
+
+STRICT, FP32 = 2, 0
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_RECORDS = []
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_report():
+    yield
+    if not _RECORDS:
+        return
+    out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "parity_r02.json"), "w") as f:
+        json.dump({"note": "HIP path vs CPU oracle at full BASELINE sizes; written by tests/test_gpu_parity_report.py",
+                   "records": _RECORDS}, f, indent=1)
+
+
+def _rec(config, build, content, output, got, want):
+    r = {"config": config, "build": build, "content": content, "output": output, "n_total": int(want.size)}
+    if want.dtype == np.uint8:
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        r["max_lsb"] = int(d.max())
+        r["n_diff"] = int((d != 0).sum())
+        r["n_gt1"] = int((d > 1).sum())
+    else:
+        g32, w32 = got.astype(np.float32), want.astype(np.float32)
+        d = np.abs(g32 - w32)
+        r["max_abs"] = float(np.nanmax(d))
+        r["n_diff"] = int((g32.view(np.uint32) != w32.view(np.uint32)).sum()) if got.dtype == np.float32 else int((got != want).sum())
+        r["n_gt_1e-3"] = int((d > 1e-3).sum())
+    _RECORDS.append(r)
+    return r
+
+
+GEN = {"structured": synth.structured_u8, "random": synth.random_u8}
+
+
+def _nis_want(img8, ow, oh, sharp, radius):
+    import openvr_fsr_amd as A
+    ih, iw = img8.shape[:2]
+    cs, cu = A.nis_coefs()
+    ok, cfg = A.nis_scaler_config(sharp, iw, ih, ow, oh)
+    assert ok
+    centre, rad = O.mask_constants(ow, oh, radius)
+    return O.nis_upscale(O.unorm8_to_float(img8), ow, oh, O.nis_block(cfg, centre, rad, 0), cs, cu)
+
+
+@pytest.mark.parametrize("content", ["structured", "random"])
+def test_c1_easu_only(gpu, content):
+    """C1: single left eye 1683x1869 -> 2244x2492 RGBA8, EASU only."""
+    iw, ih, ow, oh = 1683, 1869, 2244, 2492
+    img8 = GEN[content](iw, ih, synth.seed_for(0, 0))
+    want = O.easu(O.unorm8_to_float(img8), ow, oh)
+    want8 = O.float_to_unorm8(want)
+    r = _rec("C1", "strict", content, "float", run_gpu(img8, ow, oh, np.float32, precision=STRICT, stage_mask=1), want)
+    assert r["n_diff"] == 0
+    r = _rec("C1", "product", content, "float", run_gpu(img8, ow, oh, np.float32, precision=FP32, stage_mask=1), want)
+    assert r["max_abs"] <= 2e-5, r
+    r = _rec("C1", "product", content, "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=FP32, stage_mask=1), want8)
+    assert r["max_lsb"] <= 1 and r["n_diff"] <= 1e-4 * r["n_total"], r
+
+
+@pytest.mark.parametrize("cfg,iw,ih,ow,oh,radius", [("C2", 1683, 1869, 2244, 2492, 2.0), ("C2r", 1683, 1869, 2244, 2492, 0.5),
+                                                     ("C4", 2244, 2492, 2916, 3240, 2.0)])
+@pytest.mark.parametrize("content", ["structured", "random"])
+def test_fsr_pipeline(gpu, cfg, iw, ih, ow, oh, radius, content):
+    """C2 / C2r (shipped radius 0.5) / C4 (renderScale 1.3 shape): EASU -> UNORM8 -> RCAS -> UNORM8, and the same
+    pipeline with float intermediate and output (the form north_star's 1e-3 is meaningful on)."""
+    if cfg != "C2" and content == "random":
+        pytest.skip("random content is covered at C2 (C1, C3 as well)")
+    img8 = GEN[content](iw, ih, synth.seed_for(0, 1))
+    want8 = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9, radius=radius, eye=1)
+    _, wantf = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9, radius=radius, eye=1, quantize_intermediate=False, want_float=True)
+    kw = dict(eye=1, sharpness=0.9, radius=radius)
+    r = _rec(cfg, "strict", content, "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=STRICT, **kw), want8)
+    assert r["n_diff"] == 0
+    r = _rec(cfg, "strict", content, "float (float intermediate)",
+             run_gpu(img8, ow, oh, np.float32, precision=STRICT, quantize_intermediate=0, fused=0, **kw), wantf)
+    assert r["n_diff"] == 0
+    r = _rec(cfg, "product", content, "float (float intermediate)",
+             run_gpu(img8, ow, oh, np.float32, precision=FP32, quantize_intermediate=0, fused=0, **kw), wantf)
+    assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
+    r = _rec(cfg, "product", content, "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=FP32, **kw), want8)
+    assert r["max_lsb"] <= 5 and r["n_diff"] <= 1e-4 * r["n_total"], r
+    # root cause of the > 1 LSB tail, measured: bytes of the 8-bit intermediate that differ from the oracle's
+    if radius >= 2.0:
+        mid_want = O.float_to_unorm8(O.easu(O.unorm8_to_float(img8), ow, oh))
+        r = _rec(cfg, "product", content, "unorm8 intermediate (EASU pass)",
+                 run_gpu(img8, ow, oh, np.uint8, precision=FP32, stage_mask=1, **kw), mid_want)
+        assert r["max_lsb"] <= 1, r
+
+
+@pytest.mark.parametrize("cfg,radius", [("C3", 2.0), ("C3r", 0.5)])
+@pytest.mark.parametrize("content", ["structured", "random"])
+def test_nis_scaler(gpu, cfg, radius, content):
+    """C3 / C3r: NVScaler 1683x1869 -> 2244x2492."""
+    if cfg == "C3r" and content == "random":
+        pytest.skip("random content is covered at C3")
+    iw, ih, ow, oh = 1683, 1869, 2244, 2492
+    img8 = GEN[content](iw, ih, synth.seed_for(1, 0))
+    want = _nis_want(img8, ow, oh, 0.9, radius)
+    want8 = O.float_to_unorm8(want)
+    kw = dict(use_nis=1, sharpness=0.9, radius=radius)
+    r = _rec(cfg, "strict", content, "float", run_gpu(img8, ow, oh, np.float32, precision=STRICT, **kw), want)
+    assert r["n_diff"] == 0
+    r = _rec(cfg, "product", content, "float", run_gpu(img8, ow, oh, np.float32, precision=FP32, **kw), want)
+    assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
+    r = _rec(cfg, "product", content, "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=FP32, **kw), want8)
+    assert r["max_lsb"] <= 1, r
+
+
+def test_c5_masked_half(gpu):
+    """C5: radius-masked EASU+RCAS, 2370x2370 -> 3160x3160, RGBA16F in, half intermediate, RGBA16F out."""
+    iw, ih, ow, oh = 2370, 2370, 3160, 3160
+    imgh = (synth.structured_u8(iw, ih, 77).astype(np.float32) / 255.0).astype(np.float16)
+    centre, rad = O.mask_constants(ow, oh, 0.5)
+    e = O.easu(imgh.astype(np.float32), ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
+    e16 = e.astype(np.float16).astype(np.float32)
+    want = O.rcas(e16, O.rcas_con(0.9), centre, rad).astype(np.float16)
+    r = _rec("C5", "strict", "structured", "half", run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5), want)
+    assert r["n_diff"] == 0
+    r = _rec("C5", "product", "structured", "half", run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5), want)
+    # a half intermediate has 2^-11 relative steps: where the product build's EASU lands on the other side of a half
+    # rounding boundary the intermediate moves by one half ulp (<= 4.9e-4 below 1.0) and RCAS amplifies it up to 4x
+    assert r["max_abs"] <= 4e-3 and r["n_gt_1e-3"] <= 1e-5 * r["n_total"], r
