@@ -144,6 +144,89 @@ KERNEL(k_cndmask, VCND8)
     asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a6), "v"(b6) : "vcc"); \
     asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a7), "v"(b7) : "vcc");
 KERNEL(k_cmp_lt_f32, VCMP8)
+// round 2: integer multiplies (address arithmetic of the staging loops), selects on an SGPR mask, DPP moves, 64-bit adds
+KERNEL(k_mul_lo_u32, V8_2("v_mul_lo_u32"))
+KERNEL(k_mul_hi_u32, V8_2("v_mul_hi_u32"))
+KERNEL(k_med3_i32, V8("v_med3_i32"))
+KERNEL(k_sub_f32, V8_2("v_sub_f32"))
+#define VFMACL8                                                      \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a0) : "v"(b0)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a1) : "v"(b1)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a2) : "v"(b2)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a3) : "v"(b3)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a4) : "v"(b4)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a5) : "v"(b5)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a6) : "v"(b6)); \
+    asm volatile("v_fma_f32 %0, %0, %1, %0 clamp" : "+v"(a7) : "v"(b7));
+KERNEL(k_fma_f32_clamp, VFMACL8)
+#define VFMAABS8                                                      \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a0) : "v"(b0)); \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a1) : "v"(b1)); \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a2) : "v"(b2)); \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a3) : "v"(b3)); \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a4) : "v"(b4)); \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a5) : "v"(b5)); \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a6) : "v"(b6)); \
+    asm volatile("v_fma_f32 %0, |%0|, %1, -%0" : "+v"(a7) : "v"(b7));
+KERNEL(k_fma_f32_mods, VFMAABS8)
+#define VCNDS8                                                                  \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a0) : "v"(b0), "s"(m)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a1) : "v"(b1), "s"(m)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a2) : "v"(b2), "s"(m)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a3) : "v"(b3), "s"(m)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a4) : "v"(b4), "s"(m)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a5) : "v"(b5), "s"(m)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a6) : "v"(b6), "s"(m)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(a7) : "v"(b7), "s"(m));
+__global__ __launch_bounds__(256) void k_cndmask_sgpr(float *out, int iters, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * .5f, b3 = a3 * .5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;
+    unsigned long long m = __builtin_amdgcn_ballot_w64(seed + threadIdx.x > 40.f);
+    for (int i = 0; i < iters; ++i) { REP8(VCNDS8) }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7;
+}
+#define VDPP8(CTRL)                                                            \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a0) : "v"(b0)); \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a1) : "v"(b1)); \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a2) : "v"(b2)); \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a3) : "v"(b3)); \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a4) : "v"(b4)); \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a5) : "v"(b5)); \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a6) : "v"(b6)); \
+    asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a7) : "v"(b7));
+KERNEL(k_mov_dpp_row_shr, VDPP8("row_shr:1"))
+KERNEL(k_mov_dpp_wave_shr, VDPP8("wave_shr:1"))
+#define VADDDPP8                                                            \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0) : "v"(b0)); \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a1) : "v"(b1)); \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a2) : "v"(b2)); \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a3) : "v"(b3)); \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a4) : "v"(b4)); \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a5) : "v"(b5)); \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a6) : "v"(b6)); \
+    asm volatile("v_add_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a7) : "v"(b7));
+KERNEL(k_add_f32_dpp, VADDDPP8)
+#define VBPERM8                                                            \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(addr)); \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a1) : "v"(addr)); \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a2) : "v"(addr)); \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a3) : "v"(addr)); \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a4) : "v"(addr)); \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a5) : "v"(addr)); \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a6) : "v"(addr)); \
+    asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(a7) : "v"(addr));
+KERNEL(k_ds_bpermute, VBPERM8)
+#define VPKCL4                                                                                    \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p0) : "v"(q0));                                        \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p1) : "v"(q1));                                        \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p2) : "v"(q2));                                        \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p3) : "v"(q3));                                        \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p4) : "v"(q4));                                        \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p5) : "v"(q5));                                        \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p6) : "v"(q6));                                        \
+    asm volatile("v_pk_fma_f32 %0, %0, %1, %0 clamp" : "+v"(p7) : "v"(q7));
+PKERNEL(k_pk_fma_f32_clamp, VPKCL4)
 PKERNEL(k_pk_fma_f32, P4("v_pk_fma_f32"))
 PKERNEL(k_pk_mul_f32, P4_2("v_pk_mul_f32"))
 PKERNEL(k_pk_add_f32, P4_2("v_pk_add_f32"))
@@ -225,6 +308,10 @@ int main()
         {"v_cvt_u32_f32", k_cvt_u32_f32, 64}, {"v_cvt_f32_u32", k_cvt_f32_u32, 64}, {"v_floor_f32", k_floor_f32, 64}, {"v_mov_b32", k_mov_b32, 64},
         {"v_fmac_f32", k_fmac_f32, 64}, {"v_mul_u32_u24", k_mul_u32_u24, 64}, {"v_mad_u32_u24", k_mad_u32_u24, 64},
         {"v_cndmask_b32", k_cndmask, 64}, {"v_cmp_lt_f32", k_cmp_lt_f32, 64},
+        {"v_mul_lo_u32", k_mul_lo_u32, 64}, {"v_mul_hi_u32", k_mul_hi_u32, 64}, {"v_med3_i32", k_med3_i32, 64}, {"v_sub_f32", k_sub_f32, 64},
+        {"v_fma_f32 clamp", k_fma_f32_clamp, 64}, {"v_fma_f32 |a|,-c mods", k_fma_f32_mods, 64}, {"v_pk_fma_f32 clamp", k_pk_fma_f32_clamp, 64},
+        {"v_cndmask_b32 (sgpr mask)", k_cndmask_sgpr, 64}, {"v_mov_b32_dpp row_shr:1", k_mov_dpp_row_shr, 64},
+        {"v_mov_b32_dpp wave_shr:1", k_mov_dpp_wave_shr, 64}, {"v_add_f32_dpp row_shr:1", k_add_f32_dpp, 64}, {"ds_bpermute_b32 (+wait)", k_ds_bpermute, 64},
         {"ds_read_b32", k_ds_read_b32, 64}, {"ds_read_b64", k_ds_read_b64, 64}, {"ds_read_b128", k_ds_read_b128, 64},
     };
     const int iters = 4000;
