@@ -39,15 +39,24 @@ size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
     return col + ncell * 16 + ncell * 4;
 }
 
+template <int I, int O, bool M>
+static void easu_fast_go(int pitch, const EasuArgs &a, dim3 grid, hipStream_t s)
+{
+    const size_t lds = (size_t)pitch * a.cellsH * 36; // colour + analysis (float4) + luma planes
+    if (pitch == 28) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 28, M>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 32, M>), grid, dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 40, M>), grid, dim3(kThreads), lds, s, a);
+}
+
 template <int I, int O>
 static hipError_t easu_go(bool strict, const EasuArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
     const int pitch = easu_kernel_pitch(a.cellsW);
+    const bool masked = a.m.mode[0] != MASK_ALL_INSIDE || a.m.mode[1] != MASK_ALL_INSIDE;
     if (strict) hipLaunchKernelGGL((ovrfsr_strict::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
-    else if (pitch == 28) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 28>), grid, dim3(kThreads), (size_t)28 * a.cellsH * 36, s, a);
-    else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, a);
-    else if (pitch == 40) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, a);
-    else hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 0) hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    else if (masked) easu_fast_go<I, O, true>(pitch, a, grid, s);
+    else easu_fast_go<I, O, false>(pitch, a, grid, s);
     return hipGetLastError();
 }
 template <int I, int O>
