@@ -28,7 +28,7 @@ extern "C" {
 #define OVRFSR_API
 #endif
 
-#define OVRFSR_ABI_VERSION 1u
+#define OVRFSR_ABI_VERSION 2u /* 2: ovrfsr_average_gpu_time_ms added; precision value 1 (never built) removed */
 
 typedef enum ovrfsr_status {
     OVRFSR_OK = 0,
@@ -65,13 +65,16 @@ typedef enum ovrfsr_format {
 
 /* Arithmetic the kernels run in.  The reference only ever compiles the fp32 bodies
  * (`//#define A_HALF`, src/fsr/fsr_easu.hlsl:3).
- *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp)
- *   FP16         packed-half tap arithmetic (v_pk_*_f16), fp32 accumulation where it matters
+ *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp): the product build
  *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
- *                to the CPU oracle; a validation build, not a fast one */
+ *                to the CPU oracle; a validation build, not a fast one
+ * There is no packed-half arithmetic mode (value 1 was reserved for one in ABI 1 and is rejected with
+ * OVRFSR_ERR_INVALID_ARGUMENT by ovrfsr_create / ovrfsr_set_config): on gfx950 v_pk_*_f16 issues at the rate of
+ * v_pk_*_f32 (profiles/r02_valu_issue_rates.txt), the fp32 kernels already process two taps per packed instruction, and
+ * half accumulation of 12 taps misses the 1e-3 tolerance -- the "fp16" of BASELINE configs C2/C3/C5 is served by fp32
+ * arithmetic with RGBA16F images and a half intermediate where the config asks for packed-half I/O. */
 typedef enum ovrfsr_precision {
     OVRFSR_PRECISION_FP32 = 0,
-    OVRFSR_PRECISION_FP16 = 1,
     OVRFSR_PRECISION_FP32_STRICT = 2
 } ovrfsr_precision;
 

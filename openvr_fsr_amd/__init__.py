@@ -8,7 +8,7 @@ package: if the HIP library is missing or no gfx950 device is present, calls rai
 from ._capi import (  # noqa: F401
     Config, Image, Bounds, OvrFsrError, library, library_path, have_library,
     FORMAT_RGBA8, FORMAT_RGBA16F, FORMAT_RGBA32F, FORMAT_RGB10A2, FORMAT_BGRA8,
-    PRECISION_FP32, PRECISION_FP16, PRECISION_FP32_STRICT,
+    PRECISION_FP32, PRECISION_FP32_STRICT,
     EYE_LEFT, EYE_RIGHT,
     easu_con, rcas_con, mask_constants, nis_scaler_config, nis_sharpen_config, nis_coefs, output_size, config_from_json,
 )

@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 FORMAT_RGBA8, FORMAT_RGBA16F, FORMAT_RGBA32F, FORMAT_RGB10A2, FORMAT_BGRA8 = 0, 1, 2, 3, 4
-PRECISION_FP32, PRECISION_FP16, PRECISION_FP32_STRICT = 0, 1, 2
+PRECISION_FP32, PRECISION_FP32_STRICT = 0, 2
 EYE_LEFT, EYE_RIGHT = 0, 1
 
 STATUS = {0: "OK", 1: "INVALID_ARGUMENT", 2: "UNSUPPORTED", 3: "HIP", 4: "NO_DEVICE", 5: "DISABLED", 6: "OUT_OF_MEMORY"}
@@ -102,7 +102,7 @@ def library():
     L.ovrfsr_nis_coef_usm.restype = f32p
     L.ovrfsr_config_from_json.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Config)]
     L.ovrfsr_save_ppm.argtypes = [C.POINTER(Image), C.c_char_p, C.c_void_p]
-    if L.ovrfsr_abi_version() != 1:
+    if L.ovrfsr_abi_version() != 2:
         raise OvrFsrError(1, "ABI version mismatch")
     _LIB = L
     return L

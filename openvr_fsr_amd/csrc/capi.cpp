@@ -14,6 +14,13 @@ struct ovrfsr_ctx {
 
 namespace {
 bool config_ok(const ovrfsr_config *cfg) { return cfg && cfg->struct_size == sizeof(ovrfsr_config); }
+// what create / set_config accept: a ctx is never built around a configuration no kernel exists for (and so never
+// disables itself over one at the first apply)
+bool config_valid(const ovrfsr_config *cfg)
+{
+    return config_ok(cfg) && (cfg->precision == OVRFSR_PRECISION_FP32 || cfg->precision == OVRFSR_PRECISION_FP32_STRICT) &&
+           cfg->stage_mask >= 0 && cfg->stage_mask <= 2 && cfg->fused >= -1 && cfg->fused <= 1;
+}
 
 // Nothing may unwind through the extern "C" boundary (header: "nothing here throws"): host-side containers of the launch
 // manager can throw std::bad_alloc, which becomes a status like every other failure.
@@ -75,7 +82,7 @@ OVRFSR_API int ovrfsr_output_size(const ovrfsr_config *cfg, uint32_t in_w, uint3
 
 OVRFSR_API int ovrfsr_create(int device, const ovrfsr_config *cfg, ovrfsr_ctx **out_ctx)
 {
-    if (!out_ctx || !config_ok(cfg)) return OVRFSR_ERR_INVALID_ARGUMENT;
+    if (!out_ctx || !config_valid(cfg)) return OVRFSR_ERR_INVALID_ARGUMENT;
     *out_ctx = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return OVRFSR_ERR_NO_DEVICE;
@@ -101,7 +108,7 @@ OVRFSR_API void ovrfsr_destroy(ovrfsr_ctx *ctx)
 
 OVRFSR_API int ovrfsr_set_config(ovrfsr_ctx *ctx, const ovrfsr_config *cfg)
 {
-    if (!ctx || !config_ok(cfg)) return OVRFSR_ERR_INVALID_ARGUMENT;
+    if (!ctx || !config_valid(cfg)) return OVRFSR_ERR_INVALID_ARGUMENT; // the ctx keeps its previous configuration
     return guarded([&] { return ctx->pp->SetConfig(*cfg); });
 }
 

@@ -7,7 +7,7 @@
 namespace ovrfsr {
 
 enum : int { FMT_RGBA8 = 0, FMT_RGBA16F = 1, FMT_RGBA32F = 2, FMT_RGB10A2 = 3 };
-enum : int { PREC_FP32 = 0, PREC_FP16 = 1, PREC_FP32_STRICT = 2 };
+enum : int { PREC_FP32 = 0, PREC_FP32_STRICT = 2 }; // ovrfsr_precision (1 is not a mode)
 
 // mask_mode: every 16x16 group inside the radius / every group outside / mixed (test per group)
 enum : uint32_t { MASK_ALL_INSIDE = 0, MASK_ALL_OUTSIDE = 1, MASK_MIXED = 2 };

@@ -222,7 +222,7 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
     if (!doUpscale_ && (ow != in.width || oh != in.height))
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "sharpen-only needs output size == input size");
     if (cfg_.precision != OVRFSR_PRECISION_FP32 && cfg_.precision != OVRFSR_PRECISION_FP32_STRICT)
-        return Fail(OVRFSR_ERR_UNSUPPORTED, "precision not built yet");
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "unknown precision");
 
     for (int eye = 0; eye < 2; ++eye) {
         mask_constants(centre_[eye], radius_, ow, oh, cfg_.proj_centre, cfg_.radius, textureContainsOnlyOneEye_ ? 1 : 0, eye);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     L = A.library()
-    assert L.ovrfsr_abi_version() == 1
+    assert L.ovrfsr_abi_version() == 2
     cfg = A.Config.default()
     assert cfg.struct_size == C.sizeof(A.Config) == 80
     assert C.sizeof(A.Image) == 24 and C.sizeof(A.Bounds) == 16
@@ -76,6 +76,18 @@ def test_bad_struct_size_is_rejected():
     assert A.library().ovrfsr_output_size(C.byref(cfg), 10, 10, C.byref(w), C.byref(h)) == 1
     ctx = C.c_void_p()
     assert A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx)) == 1 and not ctx
+
+
+def test_create_rejects_configurations_no_kernel_exists_for():
+    """precision 1 (a packed-half mode ABI 1 reserved and never built), unknown stage masks / fused values: rejected at
+    create with INVALID_ARGUMENT before any device is touched, instead of a ctx that disables itself at the first apply."""
+    ctx = C.c_void_p()
+    for kw in (dict(precision=1), dict(precision=7), dict(stage_mask=3), dict(fused=2)):
+        cfg = A.Config.default(fsr_enabled=1, **kw)
+        assert A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx)) == 1 and not ctx
+    assert not hasattr(A, "PRECISION_FP16")
+    hdr = open(os.path.join(ROOT, "include", "openvr_fsr_amd.h")).read()
+    assert "OVRFSR_PRECISION_FP16" not in hdr.split("typedef enum ovrfsr_precision")[1].split("}")[0]
 
 
 def test_null_ctx_is_an_error_not_a_crash():
