@@ -171,6 +171,29 @@ struct SamplerState {};
 
 // A float RGBA image (4 floats per texel) bound as Texture2D<float4>; linear/clamp sampler only
 // (that is what a NULL sampler slot gives on D3D11 -- SURVEY.md appendix A).
+//
+// The four fixed-function behaviours restated here, where they are specified, and where each is pinned in isolation
+// (tests/test_d3d_semantics.py through oracle/shim_probe.cpp).  The D3D11.3 Functional Specification is public
+// (microsoft.github.io/DirectX-Specs); chapter/section titles below are quoted from memory -- this container has no
+// network -- so the d3d11.h constants and the reference's own comments are given as the checkable anchors:
+//  (1) Gather4 footprint and component order: spec "gather4" instruction (Shader Model 4.1+/5 instruction reference,
+//      ch. 22): the 2x2 bilinear footprint of the unnormalised coordinate u*W-0.5, returned as
+//      (-,+),(+,+),(+,-),(-,-) = .x bottom-left, .y bottom-right, .z top-right, .w top-left (same order in the HLSL docs
+//      of Texture2D::Gather).  The reference relies on exactly this: "Gather 4 ordering: a b / r g" and the names
+//      bczz / ijfe / klhg / zzon, src/fsr/ffx_fsr1.h:333-360.  Test: test_gather_component_order,
+//      test_easu_gather_positions_match_the_tap_comments.
+//  (2) Clamp addressing (D3D11_TEXTURE_ADDRESS_CLAMP, the default sampler state's mode): spec "Texture Addressing"
+//      (sampler state, ch. 7.18): every texel index of the footprint is clamped to [0, size-1] individually.
+//      Test: test_clamp_addressing.
+//  (3) ld / Texture2D::Load / operator[] out of range: spec "ld" instruction: "out of bounds addresses ... return 0 in
+//      all components" (the FSR sources depend on it: RCAS's border taps).  Test: test_load_out_of_bounds_is_zero,
+//      test_oracle_rcas_border_equals_explicit_zero_ring.
+//  (4) Bilinear weights: spec "Texture Filtering / fixed point texel addressing": texel-space coordinates are converted to
+//      fixed point with D3D11_SUBTEXEL_FRACTIONAL_BIT_COUNT = 8 fractional bits (d3d11.h; the same value is reported as
+//      sub-texel precision by every D3D11 hardware tier), round to nearest, before the footprint and the weights are
+//      derived.  Test: test_bilinear_has_8_subtexel_bits, test_oracle_bilinear_fallback_equals_shim.
+//  UNORM stores (RWTexture2D<unorm float4>): spec "Floating point to UNORM conversion": saturate (NaN -> 0), scale,
+//  +0.5, truncate; FSR documents the same at src/fsr/ffx_fsr1.h:1075-1080.  Test: test_unorm_store.
 struct Texture2D {
     const float *px = nullptr;
     int w = 0, h = 0;

@@ -57,6 +57,26 @@ def lib():
     return _LIB
 
 
+_PROBE = None
+
+
+def shim_probe():
+    """oracle/libshimprobe.so: the D3D11 fixed-function behaviours of hlsl_shim.hpp, one entry point each."""
+    global _PROBE
+    if _PROBE is None:
+        so = os.path.join(HERE, "libshimprobe.so")
+        srcs = [os.path.join(HERE, f) for f in ("shim_probe.cpp", "hlsl_shim.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+            subprocess.check_call(["make", "-C", HERE, "-B", "libshimprobe.so"], stdout=subprocess.DEVNULL)
+        P = C.CDLL(so)
+        P.probe_gather.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, f32p]
+        P.probe_sample.argtypes = [f32p, C.c_int, C.c_int, C.c_float, C.c_float, f32p]
+        P.probe_load.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
+        P.probe_unorm_store.argtypes = [f32p, f32p]
+        _PROBE = P
+    return _PROBE
+
+
 def ref_path():
     return os.path.join(HERE, "_ref", "libovrfsr_ref.so")
 
