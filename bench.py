@@ -295,7 +295,7 @@ def dominant_kernels(workload):
     inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[workload]
     rgba8 = dtype == torch.uint8
     if (inW, inH) == (outW, outH):
-        return ["nis_sharpen_kernel"] if use_nis else ["rcas_direct_kernel"]
+        return ["nis_sharpen_kernel"] if use_nis else ["rcas_dpp_kernel"]
     if use_nis:   # NVScaler (+ the DirectCopy kernel of the groups outside the radius, concurrent)
         return ["nis_scaler_kernel"] + ((["outside_staged_kernel"] if rgba8 else ["nis_outside_kernel"]) if radius < 2.0 else [])
     if radius < 2.0:  # tiles touching the radius: EASU+RCAS (RGBA8) or the fused kernel; the rest in final form, concurrent

@@ -1,6 +1,7 @@
 // fsr_kernels.hip -- instantiates the gfx950 FSR1 kernels twice (product build and strict
 // validation build, see fsr_kernels.inc) and exposes typed launchers to the host launch manager.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "fsr_params.h"
 #include "fsr_launch.h"
@@ -62,8 +63,21 @@ static hipError_t easu_go(bool strict, const EasuArgs &a, dim3 grid, size_t lds,
 template <int I, int O>
 static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t s)
 {
-    if (strict) hipLaunchKernelGGL((ovrfsr_strict::rcas_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((ovrfsr_fast::rcas_direct_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    // OVRFSR_RCAS_DPP=0: A/B switch back to the per-lane-loads kernel (diagnostic)
+    static const bool dpp = [] { const char *e = std::getenv("OVRFSR_RCAS_DPP"); return !(e && e[0] == '0'); }();
+    const bool unmasked = !a.tileList && a.m.mode[0] == MASK_ALL_INSIDE && a.m.mode[1] == MASK_ALL_INSIDE;
+    if (strict) {
+        hipLaunchKernelGGL((ovrfsr_strict::rcas_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    } else if constexpr (I == FMT_RGBA8 && O != FMT_RGB10A2) {
+        if (dpp && unmasked) {
+            const uint32_t tx = (uint32_t)(a.v.outW + kRcasDppTileW - 1) / kRcasDppTileW, ty = (uint32_t)(a.v.outH + kRcasDppTileH - 1) / kRcasDppTileH;
+            hipLaunchKernelGGL((ovrfsr_fast::rcas_dpp_kernel<O>), dim3(tx * ty, 1, grid.z), dim3(kThreads), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((ovrfsr_fast::rcas_direct_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+        }
+    } else {
+        hipLaunchKernelGGL((ovrfsr_fast::rcas_direct_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
+    }
     return hipGetLastError();
 }
 

@@ -15,6 +15,8 @@ enum : uint32_t { MASK_ALL_INSIDE = 0, MASK_ALL_OUTSIDE = 1, MASK_MIXED = 2 };
 constexpr int kTileW = 32;  // output pixels per workgroup tile (two 16-px mask groups wide)
 constexpr int kTileH = 32;
 constexpr int kThreads = 256;
+constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
+constexpr int kRcasDppTileH = 16; //                  4 waves x 4 rows per lane
 
 struct BatchView {          // image i of a batch lives at base + i*stride
     const uint8_t *in;
