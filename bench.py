@@ -465,6 +465,8 @@ def parse_args(argv=None):
     ap.add_argument("--pmc", default="auto", choices=["auto", "off"],
                     help="auto: read HBM-traffic and VALU counters in this run (rocprofv3 --pmc child passes, ~1 min)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="testing only: map shard i to device i %% device_count (exercise the N>1 launchers on a box with fewer GPUs)")
     ap.add_argument("--content", default="structured", choices=["structured", "random"],
                     help="synthetic eye content: structured (gradients+edges+noise, default) or uniform random")
     return ap.parse_args(argv)
@@ -486,7 +488,9 @@ def main():
     if args.pmc_child:
         return pmc_child(args)
     world, rank, devices, first_shard = plan(args, os.environ)
-    assert len(devices) <= torch.cuda.device_count(), "--gpus %d but only %d device(s) visible" % (len(devices), torch.cuda.device_count())
+    if args.oversubscribe:
+        devices = [d % torch.cuda.device_count() for d in devices]
+    assert max(devices) < torch.cuda.device_count(), "--gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count())
     cross = None
     if world > 1:
         import torch.distributed as dist
@@ -522,6 +526,8 @@ def main():
                        "launcher": "torchrun, one rank per GPU, gloo timing barrier" if world > 1
                                    else "one process, %d device(s), one host thread + stream per device" % len(devices),
                        "per_device_ms_per_step": [round(m / args.steps, 4) for m in dev_ms],
+                       **({"oversubscribed": "TEST RUN: %d shards on %d device(s), not a scaling measurement" % (n_gpus, torch.cuda.device_count())}
+                          if args.oversubscribe else {}),
                        "parallelism": "batch sharded over %d GPU(s), no collective" % n_gpus},
             "roofline": roof, "cpu_baseline": cpu,
         }
