@@ -157,8 +157,10 @@ static hipError_t fused_go(int mid_fmt, bool strict, const FusedArgs &a, dim3 gr
     }
 }
 
-hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles)
+hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
+    FusedArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const bool strict = prec == PREC_FP32_STRICT;
     if (!strict && easu_fast_pitch(a.cellsW) == 0) return hipErrorInvalidValue;
@@ -211,8 +213,10 @@ static hipError_t outside_staged_go(int mid_fmt, const OutsideArgs &a, dim3 grid
 template <int I, int O> static hipError_t outside_staged_go32(int mid_fmt, const OutsideArgs &a, dim3 grid, hipStream_t s) { return outside_staged_go<32, I, O>(mid_fmt, a, grid, s); }
 template <int I, int O> static hipError_t outside_staged_go24(int mid_fmt, const OutsideArgs &a, dim3 grid, hipStream_t s) { return outside_staged_go<24, I, O>(mid_fmt, a, grid, s); }
 
-hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt, const OutsideArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s)
+hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt, const OutsideArgs &a_in, uint32_t nTiles, uint32_t batch, hipStream_t s)
 {
+    OutsideArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || !a.bilX || !a.bilY || nTiles == 0 || !outside_staged_ok(a.v, in_fmt)) return hipErrorInvalidValue;
     if (a.lds_cols < 2 || a.lds_cols > 36 || a.lds_rows < 2 || a.lds_rows > 34) return hipErrorInvalidValue;
     const dim3 grid(nTiles, 1, batch);
@@ -222,8 +226,10 @@ hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt
 }
 
 // nTiles blocks, each resolving tile a.tileList[block]: tiles entirely outside the radius (product build only).
-hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s)
+hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuArgs &a_in, uint32_t nTiles, uint32_t batch, hipStream_t s)
 {
+    EasuArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || nTiles == 0) return hipErrorInvalidValue;
     if (a.bilX && a.bilY && outside_staged_ok(a.v, in_fmt)) {
         OutsideArgs o;
@@ -255,8 +261,10 @@ hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t s
     return hipGetLastError();
 }
 
-hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles)
+hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
+    EasuArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const bool strict = prec == PREC_FP32_STRICT;
     const dim3 grid(a.tileList ? nTiles : a.tilesX * a.tilesY, 1, batch);
@@ -264,8 +272,11 @@ hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uin
     OVRFSR_DISPATCH_FMT(easu_go, strict, a, grid, lds, s)
 }
 
-hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles)
+hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
+    RcasArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
+    a.dppTilesXMagic = div_magic((uint32_t)(a.v.outW + kRcasDppTileW - 1) / kRcasDppTileW);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const bool strict = prec == PREC_FP32_STRICT;
     if (a.tileList && (strict || nTiles == 0)) return hipErrorInvalidValue; // lists are a product-build feature

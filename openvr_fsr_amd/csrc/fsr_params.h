@@ -18,6 +18,10 @@ constexpr int kThreads = 256;
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
 constexpr int kRcasDppTileH = 16; //                  4 waves x 4 rows per lane
 
+// q = n / d for n*d < 2^32 as one scalar multiply-high: magic = floor(2^32/d) + 1 (0 = "d is 1").  Tile indices are
+// workgroup-uniform, but the hardware has no scalar divide: `tile / tilesX` costs ~20 VALU instructions per thread.
+static inline uint32_t div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
+
 struct BatchView {          // image i of a batch lives at base + i*stride
     const uint8_t *in;
     uint8_t *out;
@@ -46,6 +50,7 @@ struct EasuArgs {
     MaskArgs m;
     int32_t cellsW, cellsH; // LDS input tile extent (max over tiles) incl. the 1+2 apron
     uint32_t tilesX, tilesY;
+    uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const BilinTap *bilX;   // [outW], [outH] device tables for the bilinear fallback (product build)
     const BilinTap *bilY;
     const uint32_t *tileList; // optional: tile index of each block (mask-sorted launch); null = all tiles in XCD order
@@ -60,6 +65,7 @@ struct EasuArgs {
 struct OutsideArgs {
     BatchView v;
     uint32_t tilesX;          // tiles (32 x TH output pixels) per row
+    uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launcher
     const uint32_t *tileList;
     const BilinTap *bilX;     // host-built column / row taps (see BilinTap), padded by 64 entries
     const BilinTap *bilY;
@@ -73,7 +79,9 @@ struct RcasArgs {
     uint32_t debug;         // const0[3]
     MaskArgs m;
     uint32_t tilesX, tilesY;
+    uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs); product build only
+    uint32_t dppTilesXMagic;  // div_magic of rcas_dpp_kernel's own tile count per row (62-pixel tiles)
 };
 
 struct FusedArgs {
@@ -84,6 +92,7 @@ struct FusedArgs {
     MaskArgs m;
     int32_t cellsW, cellsH;
     uint32_t tilesX, tilesY;
+    uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs)
 };
 
@@ -100,6 +109,7 @@ struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) mi
     const float *coefUsm;
     int32_t cellsW, cellsH; // LDS luma/edge tile extent of the scaler (incl. 3-texel ring)
     uint32_t tilesX, tilesY;
+    uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const uint32_t *tileList; // optional mask-sorted group list (see EasuArgs)
     const BilinTap *bilX;     // DirectCopy taps of the mask-sorted outside kernel (see OutsideArgs)
     const BilinTap *bilY;

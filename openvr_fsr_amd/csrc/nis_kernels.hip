@@ -74,8 +74,10 @@ static hipError_t nis_outside_go(const NisArgs &a, dim3 grid, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_t nGroups, uint32_t batch, hipStream_t s)
+hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a_in, uint32_t nGroups, uint32_t batch, hipStream_t s)
 {
+    NisArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || nGroups == 0) return hipErrorInvalidValue;
     if (a.bilX && a.bilY && outside_staged_ok(a.v, in_fmt)) {
         OutsideArgs o;
@@ -87,16 +89,20 @@ hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_
     OVRFSR_DISPATCH_FMT(nis_outside_go, a, grid, s)
 }
 
-hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s, uint32_t nGroups)
+hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nGroups)
 {
+    NisArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const dim3 grid(a.tileList ? nGroups : a.tilesX * a.tilesY, 1, batch);
     const size_t lds = nis_scaler_lds_bytes(a.cellsW, a.cellsH);
     OVRFSR_DISPATCH_FMT(scaler_go, prec == PREC_FP32_STRICT, a, grid, lds, s)
 }
 
-hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s)
+hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a_in, uint32_t batch, hipStream_t s)
 {
+    NisArgs a = a_in;
+    a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
     const dim3 grid(a.tilesX * a.tilesY, 1, batch);
     OVRFSR_DISPATCH_FMT(sharpen_go, prec == PREC_FP32_STRICT, a, grid, s)
