@@ -16,7 +16,7 @@ constexpr int kTileW = 32;  // output pixels per workgroup tile (two 16-px mask 
 constexpr int kTileH = 32;
 constexpr int kThreads = 256;
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
-constexpr int kRcasDppTileH = 16; //                  4 waves x 4 rows per lane
+constexpr int kRcasDppTileH = 32; //                  4 waves x 8 rows per lane
 
 // q = n / d for n*d < 2^32 as one scalar multiply-high: magic = floor(2^32/d) + 1 (0 = "d is 1").  Tile indices are
 // workgroup-uniform, but the hardware has no scalar divide: `tile / tilesX` costs ~20 VALU instructions per thread.
