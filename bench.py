@@ -307,7 +307,7 @@ PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_
 PMC_CHILD_PAIRS = 4
 
 
-def pmc_counters(args, timeout_s=240):
+def pmc_counters(args, timeout_s=120):
     """HBM traffic and VALU counters of this workload's kernels, measured IN THIS RUN: bench.py re-runs itself (a few
     steps, `--pmc-child`) under `rocprofv3 --pmc <counters>`, one pass per counter group, counters only (no trace
     options -- the guide's recipe).  Returns {kernel name: {counter: mean per dispatch}} with images per dispatch, or
@@ -317,7 +317,10 @@ def pmc_counters(args, timeout_s=240):
         return None
     import csv
     agg = {}
+    failed = False
     for counters in PMC_PASSES:
+        if failed:
+            break
         tmp = tempfile.mkdtemp(prefix="ovrfsr_pmc_", dir="/tmp")
         cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                                            "--pmc-child", "--workload", args.workload, "--content", args.content, "--precision", args.precision,
@@ -337,7 +340,7 @@ def pmc_counters(args, timeout_s=240):
                     short = m.group(1) if m else k
                     agg.setdefault(short, {}).setdefault(r.get("Counter_Name"), []).append(float(r.get("Counter_Value", 0)))
         except (subprocess.SubprocessError, OSError, ValueError):
-            pass   # this pass is lost (counter group not collectable here); the others still count
+            failed = True   # this pass is lost; do not spend more wall time on a profiler that is not usable here
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     if not agg:
