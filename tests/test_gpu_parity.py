@@ -617,3 +617,54 @@ def test_plain_c_caller(gpu, tmp_path):
     assert data.startswith(b"P6\n2244 2492\n255\n") and len(data) == len(b"P6\n2244 2492\n255\n") + 2244 * 2492 * 3
     px = np.frombuffer(data[len(b"P6\n2244 2492\n255\n"):], np.uint8)
     assert px.std() > 10    # an image, not a constant
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: the reference's averaged GPU-time log, and the two product RCAS kernels agree byte for byte
+# ------------------------------------------------------------------------------------------------
+def test_average_gpu_time_ring(gpu):
+    """PostProcessor.cpp:605-626: a ring of 6 query pairs, the oldest read back after every apply, the mean of 500 readings
+    published, doubled when each eye has its own texture (one reading = one eye, the figure = one frame)."""
+    import torch
+    import openvr_fsr_amd as A
+    t = torch.from_numpy(synth.structured_u8(96, 80, 3)).cuda()
+    pp = A.PostProcessor(fsr_enabled=1, out_width=128, out_height=107, sharpness=0.9, radius=2.0, debug_mode=1)
+    out = torch.empty((107, 128, 4), dtype=torch.uint8, device="cuda")
+    assert pp.average_gpu_time_ms() == (0.0, 0)
+    for i in range(504):                       # the first reading comes from the 6th apply: 499 readings after 504 applies
+        pp.apply(i & 1, t, out=out)
+    assert pp.average_gpu_time_ms()[1] == 0
+    pp.apply(0, t, out=out)                    # 500th reading -> one mean published
+    avg, reports = pp.average_gpu_time_ms()
+    one = pp.last_gpu_time_ms()
+    assert reports == 1 and avg > 0.0
+    assert 0.5 * (2 * one) < avg < 20 * (2 * one), (avg, one)     # per FRAME: twice a per-eye reading (loose: clocks, launch gaps)
+    for i in range(500):
+        pp.apply(i & 1, t, out=out)
+    assert pp.average_gpu_time_ms()[1] == 2
+    pp.close()
+
+
+def test_rcas_dpp_kernel_equals_per_lane_loads_kernel(gpu):
+    """rcas_dpp_kernel (side taps from neighbour lanes) and rcas_direct_kernel (every lane loads its own 14 taps) are the same
+    arithmetic: identical bytes, including image borders and widths that are not a multiple of the 62-column wave tile.
+    OVRFSR_RCAS_DPP is read once per process, so each form runs in its own interpreter."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+            "from tests import synth; from tests.util import run_gpu\n"
+            "h = hashlib.sha256()\n"
+            "for (w, hgt, gen) in [(2244, 2492, synth.structured_u8), (125, 67, synth.random_u8), (61, 33, synth.extremes_u8), (63, 5, synth.random_u8)]:\n"
+            "    h.update(run_gpu(gen(w, hgt, 5), w, hgt, np.uint8, render_scale=1.0, sharpness=0.9, radius=100.0).tobytes())\n"
+            "    h.update(run_gpu(gen(w, hgt, 6), w, hgt, np.float32, render_scale=1.0, sharpness=0.3, radius=100.0).tobytes())\n"
+            "print(h.hexdigest())\n") % root
+    digests = []
+    for dpp in ("1", "0"):
+        env = dict(os.environ, OVRFSR_RCAS_DPP=dpp)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(r.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1]
