@@ -126,9 +126,9 @@ int PostProcessor::CheckImage(const ovrfsr_image *img, const char *name)
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": bad size");
     if (img->pitch_bytes < img->width * tb || (img->pitch_bytes % tb) != 0)
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": bad pitch");
-    // the RGBA8 fast paths address texels with 32-bit byte offsets (natural size: at most 16384^2 x 4 B = 1 GiB)
-    if (img->format == OVRFSR_FORMAT_RGBA8_UNORM && (uint64_t)img->pitch_bytes * img->height > 0xffffffffull)
-        return Fail(OVRFSR_ERR_UNSUPPORTED, std::string(name) + ": RGBA8 image spans more than 4 GiB (row pitch too large)");
+    // the fast paths address texels with 32-bit byte offsets off the image base (natural size: at most 16384^2 x 16 B = 4 GiB)
+    if ((uint64_t)img->pitch_bytes * img->height > 0x100000000ull)
+        return Fail(OVRFSR_ERR_UNSUPPORTED, std::string(name) + ": image spans more than 4 GiB (row pitch too large)");
     if ((reinterpret_cast<uintptr_t>(img->data) % tb) != 0)
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, std::string(name) + ": data not texel-aligned");
     return OVRFSR_OK;
