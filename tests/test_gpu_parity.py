@@ -668,3 +668,43 @@ def test_rcas_dpp_kernel_equals_per_lane_loads_kernel(gpu):
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append(r.stdout.strip().splitlines()[-1])
     assert digests[0] == digests[1]
+
+
+def test_two_ctxs_on_two_host_threads(gpu):
+    """Distinct ctxs are independent (header: "one per device; not thread-safe; distinct ctxs are independent"): two host threads,
+    each with its own ctx and its own stream on the same device, interleave applies of different configurations; every result
+    equals the single-threaded one."""
+    import threading
+    import torch
+    import openvr_fsr_amd as A
+    imgs = [synth.structured_u8(150, 120, 40 + i) for i in range(6)]
+    cfgs = [dict(fsr_enabled=1, out_width=200, out_height=160, sharpness=0.8, radius=0.6, proj_centre=(0.45, 0.5, 0.55, 0.5)),
+            dict(fsr_enabled=1, use_nis=1, out_width=200, out_height=160, sharpness=0.5, radius=2.0)]
+    want = [[run_gpu(im, 200, 160, np.uint8, eye=i & 1, **cfg) for i, im in enumerate(imgs)] for cfg in cfgs]
+    got = [[None] * len(imgs) for _ in cfgs]
+    errors = []
+
+    def worker(ci):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                pp = A.PostProcessor(**cfgs[ci])
+                for rep in range(5):
+                    for i, im in enumerate(imgs):
+                        t = torch.from_numpy(im).cuda()
+                        out = pp.apply(i & 1, t, out_dtype=torch.uint8)
+                        stream.synchronize()
+                        got[ci][i] = out.cpu().numpy()
+                pp.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(ci,)) for ci in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for ci in range(2):
+        for i in range(len(imgs)):
+            assert np.array_equal(got[ci][i], want[ci][i]), (ci, i)

@@ -151,3 +151,46 @@ def test_c5_masked_half(gpu):
     # a half intermediate has 2^-11 relative steps: where the product build's EASU lands on the other side of a half
     # rounding boundary the intermediate moves by one half ulp (<= 4.9e-4 below 1.0) and RCAS amplifies it up to 4x
     assert r["max_abs"] <= 4e-3 and r["n_gt_1e-3"] <= 1e-5 * r["n_total"], r
+
+
+@pytest.mark.parametrize("content", ["structured", "random"])
+def test_sharpen_only_configs(gpu, content):
+    """renderScale 1 at 2244x2492 (PostProcessor.cpp:586-594: no upscale stage): RCAS alone (C2s, the DPP kernel) and NVSharpen
+    alone (C3s)."""
+    import openvr_fsr_amd as A
+    w, h = 2244, 2492
+    img8 = GEN[content](w, h, synth.seed_for(2, 0))
+    centre, rad = O.mask_constants(w, h)
+    want = O.rcas(O.unorm8_to_float(img8), O.rcas_con(0.9), centre, rad)
+    kw = dict(render_scale=1.0, sharpness=0.9)
+    r = _rec("C2s", "strict", content, "float", run_gpu(img8, w, h, np.float32, precision=STRICT, **kw), want)
+    assert r["n_diff"] == 0
+    r = _rec("C2s", "product", content, "float", run_gpu(img8, w, h, np.float32, precision=FP32, **kw), want)
+    assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
+    r = _rec("C2s", "product", content, "unorm8", run_gpu(img8, w, h, np.uint8, precision=FP32, **kw), O.float_to_unorm8(want))
+    assert r["max_lsb"] <= 1, r
+    ok, cfg = A.nis_sharpen_config(0.9, w, h)
+    wantn = O.nis_sharpen(O.unorm8_to_float(img8), O.nis_block(cfg, centre, rad, 0))
+    kw = dict(use_nis=1, render_scale=1.0, sharpness=0.9)
+    r = _rec("C3s", "strict", content, "float", run_gpu(img8, w, h, np.float32, precision=STRICT, **kw), wantn)
+    assert r["n_diff"] == 0
+    r = _rec("C3s", "product", content, "float", run_gpu(img8, w, h, np.float32, precision=FP32, **kw), wantn)
+    assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
+    r = _rec("C3s", "product", content, "unorm8", run_gpu(img8, w, h, np.uint8, precision=FP32, **kw), O.float_to_unorm8(wantn))
+    assert r["max_lsb"] <= 1, r
+
+
+def test_c2_other_settings(gpu):
+    """C2's shape with the knobs a user turns: sharpness 0 and 1, an off-centre projection with a mask, the right eye, the debug
+    tint: strict bit-exact, product within the two-pass UNORM8 bound."""
+    iw, ih, ow, oh = 1683, 1869, 2244, 2492
+    img8 = synth.structured_u8(iw, ih, synth.seed_for(3, 1))
+    for name, kw in (("sharpness 0", dict(sharpness=0.0, radius=2.0)), ("sharpness 1", dict(sharpness=1.0, radius=2.0)),
+                     ("radius 0.7 off-centre debug", dict(sharpness=0.75, radius=0.7, proj=(0.42, 0.55, 0.61, 0.47), debug=1))):
+        okw = dict(sharpness=kw["sharpness"], radius=kw["radius"], eye=1, proj=kw.get("proj", (0.5,) * 4), debug=kw.get("debug", 0))
+        want8 = O.fsr_pipeline_u8(img8, ow, oh, **okw)
+        gkw = dict(eye=1, sharpness=kw["sharpness"], radius=kw["radius"], proj_centre=kw.get("proj", (0.5,) * 4), debug_mode=kw.get("debug", 0))
+        r = _rec("C2 (" + name + ")", "strict", "structured", "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=STRICT, **gkw), want8)
+        assert r["n_diff"] == 0
+        r = _rec("C2 (" + name + ")", "product", "structured", "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=FP32, **gkw), want8)
+        assert r["max_lsb"] <= 5 and r["n_diff"] <= 2e-4 * r["n_total"], r
