@@ -498,7 +498,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")   # host-side barrier + max-join only; the data path has no collective
+        # host-side barrier + max-join only; the data path has no collective.  gloo announces its connections on STDOUT
+        # ("[Gloo] Rank 0 is connected to ..."): keep stdout for the one JSON line by pointing fd 1 at stderr while it connects
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
         cross = dist.barrier
     torch.cuda.set_device(devices[0])
     shards = build_shards(len(devices), first_shard, lambda i, s: GpuShard(devices[i], s, args))
