@@ -33,7 +33,7 @@ static int easu_kernel_pitch(int cellsW) { return cellsW <= 28 ? 28 : easu_fast_
 size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 {
     if (prec != PREC_FP32_STRICT && easu_fast_pitch(cellsW) != 0)
-        return (size_t)easu_fast_pitch(cellsW) * cellsH * (16 + 16 + 4) + (size_t)easu_fast_pitch(cellsW) * 5 * 4; // pitch 32/40 (the fused kernel's; 28 fits inside) + kLumPadRows
+        return (size_t)easu_fast_pitch(cellsW) * cellsH * (16 + 16 + 4) + (size_t)easu_fast_pitch(cellsW) * kLumPadRows * 4; // pitch 32/40 (the fused kernel's; 28 fits inside) + kLumPadRows
     const bool wide = (prec == PREC_FP32_STRICT) || (in_fmt == FMT_RGBA32F) || (in_fmt == FMT_RGB10A2);
     const size_t ncell = (size_t)cellsW * cellsH;
     const size_t col = (ncell * (wide ? 16 : 8) + 15) & ~(size_t)15;
@@ -43,7 +43,7 @@ size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 template <int I, int O, bool M>
 static void easu_fast_go(int pitch, const EasuArgs &a, dim3 grid, hipStream_t s)
 {
-    const size_t lds = (size_t)pitch * a.cellsH * 36 + (size_t)pitch * 5 * 4; // colour + analysis (float4) + luma planes + kLumPadRows
+    const size_t lds = (size_t)pitch * a.cellsH * 36 + (size_t)pitch * kLumPadRows * 4; // colour + analysis (float4) + luma planes + pad rows
     if (pitch == 28) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 28, M>), grid, dim3(kThreads), lds, s, a);
     else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 32, M>), grid, dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 40, M>), grid, dim3(kThreads), lds, s, a);

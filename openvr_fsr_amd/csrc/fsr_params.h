@@ -15,6 +15,7 @@ enum : uint32_t { MASK_ALL_INSIDE = 0, MASK_ALL_OUTSIDE = 1, MASK_MIXED = 2 };
 constexpr int kTileW = 32;  // output pixels per workgroup tile (two 16-px mask groups wide)
 constexpr int kTileH = 32;
 constexpr int kThreads = 256;
+constexpr int kLumPadRows = 5;    // rows past the EASU luma plane that the 4-rows-per-lane analysis sweep may read (allocated, never written)
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
 constexpr int kRcasDppTileH = 32; //                  4 waves x 8 rows per lane
 
