@@ -55,7 +55,9 @@ static hipError_t easu_go(bool strict, const EasuArgs &a, dim3 grid, size_t lds,
     const int pitch = easu_kernel_pitch(a.cellsW);
     const bool masked = a.m.mode[0] != MASK_ALL_INSIDE || a.m.mode[1] != MASK_ALL_INSIDE;
     if (strict) hipLaunchKernelGGL((ovrfsr_strict::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
-    else if (pitch == 0) hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    // footprints wider than the fixed pitches, and the 10-bit format (a quantised destination without a near-tie guard of
+    // its own): the generic kernel, whose resolve is the reference-order one in every build
+    else if (pitch == 0 || I == FMT_RGB10A2 || O == FMT_RGB10A2) hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
     else if (masked) easu_fast_go<I, O, true>(pitch, a, grid, s);
     else easu_fast_go<I, O, false>(pitch, a, grid, s);
     return hipGetLastError();
@@ -129,7 +131,7 @@ static hipError_t fused_go3(bool strict, const FusedArgs &a, dim3 grid, size_t l
 {
     const int pitch = easu_fast_pitch(a.cellsW);
     // the EASU planes plus the 34x34 intermediate can exceed the 64 KiB default cap on dynamic LDS (160 KiB per CU)
-    auto raise = [](const void *fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+    auto raise = [](const void *fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsMax); };
     if (strict) {
         static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_strict::fused_kernel<I, M, O, 0>));
         if (once != hipSuccess) return once;

@@ -2,6 +2,7 @@
 // These play the role of the reference's constant buffers: UpscaleConstants
 // (src/postprocess/PostProcessor.cpp:276-283) and SharpenConstants (:403-407).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace ovrfsr {
@@ -16,6 +17,8 @@ constexpr int kTileW = 32;  // output pixels per workgroup tile (two 16-px mask 
 constexpr int kTileH = 32;
 constexpr int kThreads = 256;
 constexpr int kLumPadRows = 5;    // rows past the EASU luma plane that the 4-rows-per-lane analysis sweep may read (allocated, never written)
+// dynamic LDS the fused kernel may ask for: the 160 KiB of a CU minus its static LDS (the near-tie lists)
+constexpr size_t kFusedLdsMax = 156 * 1024;
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
 constexpr int kRcasDppTileH = 32; //                  4 waves x 8 rows per lane
 

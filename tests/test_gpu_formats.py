@@ -85,8 +85,8 @@ def test_fsr_rgb10a2_product_tolerance(gpu, radius):
     want = unpack10(pack10(oracle_fsr10(p, ow, oh, 0.9, radius)))
     got = unpack10(run10(p, ow, oh, torch.int32, precision=FP32, sharpness=0.9, radius=radius))
     d = np.abs(got - want)[..., :3] * 1023.0
-    # 1 LSB flips of the 10-bit intermediate, amplified <= 4x by RCAS (+1): same reasoning as the UNORM8 bound
-    assert d.max() <= 5.01 and (d > 0.5).mean() <= 4e-3, (float(d.max()), float((d > 0.5).mean()))
+    # the 10-bit EASU pass runs in the reference's operator order in every build (easu_go): only RCAS's rounding noise is left
+    assert d.max() <= 1.01 and (d > 0.5).mean() <= 4e-3, (float(d.max()), float((d > 0.5).mean()))
     assert np.array_equal(got[..., 3], want[..., 3])
 
 

@@ -4,15 +4,13 @@ Each case runs the HIP path through the C ABI and the CPU oracle on the same see
   max_abs   largest |difference| on float outputs (unit domain)
   max_lsb   largest byte difference on UNORM8 outputs
   n_diff    how many channel values differ at all, of n_total
-into gpurun_out/parity_r02.json (merged back from the GPU box; the copy under profiles/ is the committed record).
+into gpurun_out/parity_r03.json (merged back from the GPU box; the copy under profiles/ is the committed record).
 The asserts are the stated tolerances:
   strict build   bit-exact everywhere (n_diff == 0)
-  product build  float outputs max-abs <= 1e-3 (north_star), measured ~1e-5;
-                 UNORM8 outputs of ONE pass <= 1 LSB;
-                 UNORM8 outputs of EASU -> UNORM8 -> RCAS: the 8-bit intermediate differs from the oracle's in a few
-                 bytes per million (rounding ties of the product build's re-associated sum), and RCAS amplifies such a
-                 1-LSB flip by up to 1/(1-4*0.1875) = 4 (+1 for the final rounding): <= 5 LSB, on <= 2e-4 of the bytes
-                 (measured: <= 3 LSB, 0.4e-4 of the bytes on structured content, 1.0e-4 on uniform-random content).
+  product build  float outputs max-abs <= 1e-3 (north_star), measured ~3e-6;
+                 UNORM8 outputs of the EASU pass: bit-identical (n_diff == 0) -- the near-tie guard re-resolves every pixel
+                 whose re-associated result lies within 2^-9 byte of a rounding boundary in the reference's operator order;
+                 UNORM8 outputs of EASU -> UNORM8 -> RCAS and of every other single pass: <= 1 LSB.
 """
 import json
 import os
@@ -38,7 +36,7 @@ def _write_report():
         return
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "parity_r02.json"), "w") as f:
+    with open(os.path.join(out_dir, "parity_r03.json"), "w") as f:
         json.dump({"note": "HIP path vs CPU oracle at full BASELINE sizes; written by tests/test_gpu_parity_report.py",
                    "records": _RECORDS}, f, indent=1)
 
@@ -53,7 +51,8 @@ def _rec(config, build, content, output, got, want):
     else:
         g32, w32 = got.astype(np.float32), want.astype(np.float32)
         d = np.abs(g32 - w32)
-        r["max_abs"] = float(np.nanmax(d))
+        r["n_nan"] = int(np.isnan(g32).sum() + np.isnan(w32).sum())
+        r["max_abs"] = float(np.max(d))   # NaN propagates: a NaN output fails every "max_abs <=" assert
         r["n_diff"] = int((g32.view(np.uint32) != w32.view(np.uint32)).sum()) if got.dtype == np.float32 else int((got != want).sum())
         r["n_gt_1e-3"] = int((d > 1e-3).sum())
     _RECORDS.append(r)
@@ -85,7 +84,7 @@ def test_c1_easu_only(gpu, content):
     r = _rec("C1", "product", content, "float", run_gpu(img8, ow, oh, np.float32, precision=FP32, stage_mask=1), want)
     assert r["max_abs"] <= 2e-5, r
     r = _rec("C1", "product", content, "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=FP32, stage_mask=1), want8)
-    assert r["max_lsb"] <= 1 and r["n_diff"] <= 1e-4 * r["n_total"], r
+    assert r["n_diff"] == 0, r   # near-tie guard: the product build's UNORM8 EASU output is the oracle's
 
 
 @pytest.mark.parametrize("cfg,iw,ih,ow,oh,radius", [("C2", 1683, 1869, 2244, 2492, 2.0), ("C2r", 1683, 1869, 2244, 2492, 0.5),
@@ -109,13 +108,13 @@ def test_fsr_pipeline(gpu, cfg, iw, ih, ow, oh, radius, content):
              run_gpu(img8, ow, oh, np.float32, precision=FP32, quantize_intermediate=0, fused=0, **kw), wantf)
     assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
     r = _rec(cfg, "product", content, "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=FP32, **kw), want8)
-    assert r["max_lsb"] <= 5 and r["n_diff"] <= 2e-4 * r["n_total"], r
-    # root cause of the > 1 LSB tail, measured: bytes of the 8-bit intermediate that differ from the oracle's
+    assert r["max_lsb"] <= 1, r
+    # the 8-bit intermediate itself (what rounds 1-2 got wrong in ~12 bytes per million, amplified up to 4x by RCAS)
     if radius >= 2.0:
         mid_want = O.float_to_unorm8(O.easu(O.unorm8_to_float(img8), ow, oh))
         r = _rec(cfg, "product", content, "unorm8 intermediate (EASU pass)",
                  run_gpu(img8, ow, oh, np.uint8, precision=FP32, stage_mask=1, **kw), mid_want)
-        assert r["max_lsb"] <= 1, r
+        assert r["n_diff"] == 0, r
 
 
 @pytest.mark.parametrize("cfg,radius", [("C3", 2.0), ("C3r", 0.5)])
@@ -182,7 +181,7 @@ def test_sharpen_only_configs(gpu, content):
 
 def test_c2_other_settings(gpu):
     """C2's shape with the knobs a user turns: sharpness 0 and 1, an off-centre projection with a mask, the right eye, the debug
-    tint: strict bit-exact, product within the two-pass UNORM8 bound."""
+    tint: strict bit-exact, product <= 1 LSB."""
     iw, ih, ow, oh = 1683, 1869, 2244, 2492
     img8 = synth.structured_u8(iw, ih, synth.seed_for(3, 1))
     for name, kw in (("sharpness 0", dict(sharpness=0.0, radius=2.0)), ("sharpness 1", dict(sharpness=1.0, radius=2.0)),
@@ -193,4 +192,4 @@ def test_c2_other_settings(gpu):
         r = _rec("C2 (" + name + ")", "strict", "structured", "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=STRICT, **gkw), want8)
         assert r["n_diff"] == 0
         r = _rec("C2 (" + name + ")", "product", "structured", "unorm8", run_gpu(img8, ow, oh, np.uint8, precision=FP32, **gkw), want8)
-        assert r["max_lsb"] <= 5 and r["n_diff"] <= 2e-4 * r["n_total"], r
+        assert r["max_lsb"] <= 1, r
