@@ -197,7 +197,7 @@ bool outside_staged_ok(const BatchView &v, int in_fmt) { return v.inW <= v.outW 
 template <int TH, int I, int O>
 static hipError_t outside_staged_go(int mid_fmt, const OutsideArgs &a, dim3 grid, hipStream_t s)
 {
-    [[maybe_unused]] const size_t lds = (size_t)a.lds_cols * a.lds_rows * 16;
+    [[maybe_unused]] const size_t lds = (size_t)a.lds_rows * 3 * kOutsidePitch * sizeof(float); // [row][channel][kOutsidePitch]
     if constexpr (I != FMT_RGBA8) {
         return hipErrorInvalidValue;
     } else if constexpr (TH == 24) { // NIS DirectCopy

@@ -19,6 +19,7 @@ constexpr int kThreads = 256;
 constexpr int kLumPadRows = 5;    // rows past the EASU luma plane that the 4-rows-per-lane analysis sweep may read (allocated, never written)
 // dynamic LDS the fused kernel may ask for: the 160 KiB of a CU minus its static LDS (the near-tie lists)
 constexpr size_t kFusedLdsMax = 156 * 1024;
+constexpr int kOutsidePitch = 40; // outside_staged_kernel: floats per channel row of its planar LDS texel plane (>= 36 columns)
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
 constexpr int kRcasDppTileH = 32; //                  4 waves x 8 rows per lane
 
