@@ -219,9 +219,15 @@ hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt
 {
     OutsideArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
-    if (!a.tileList || !a.bilX || !a.bilY || nTiles == 0 || !outside_staged_ok(a.v, in_fmt)) return hipErrorInvalidValue;
+    if (!a.tileList || !a.tileRec || !a.bilX || !a.bilY || nTiles == 0 || !outside_staged_ok(a.v, in_fmt)) return hipErrorInvalidValue;
     if (a.lds_cols < 2 || a.lds_cols > 36 || a.lds_rows < 2 || a.lds_rows > 34) return hipErrorInvalidValue;
-    const dim3 grid(nTiles, 1, batch);
+    // persistent workgroups: block b walks list entries b, b + G, ... (G a multiple of 8: the list is XCD-banded, entry e
+    // belongs to band e % 8, so a workgroup stays in its XCD's band); OVRFSR_OUTSIDE_TPW = tiles per workgroup (tuning)
+    static const uint32_t tpw = [] { const char *e = std::getenv("OVRFSR_OUTSIDE_TPW"); const int v = e ? std::atoi(e) : 6; return (uint32_t)(v < 1 ? 1 : v); }();
+    a.nTiles = nTiles;
+    uint32_t G = ((nTiles + tpw - 1) / tpw + 7u) & ~7u;
+    if (G > nTiles) G = nTiles;
+    const dim3 grid(G, 1, batch);
     if (tileH == 24) { OVRFSR_DISPATCH_FMT3(outside_staged_go24, mid_fmt, a, grid, s) }
     if (tileH != 32) return hipErrorInvalidValue;
     OVRFSR_DISPATCH_FMT3(outside_staged_go32, mid_fmt, a, grid, s)
@@ -235,7 +241,7 @@ hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuA
     if (!a.tileList || nTiles == 0) return hipErrorInvalidValue;
     if (a.bilX && a.bilY && outside_staged_ok(a.v, in_fmt)) {
         OutsideArgs o;
-        o.v = a.v; o.tilesX = a.tilesX; o.tileList = a.tileList; o.bilX = a.bilX; o.bilY = a.bilY; o.debug = a.debug;
+        o.v = a.v; o.tilesX = a.tilesX; o.tileList = a.tileList; o.tileRec = a.tileRec; o.bilX = a.bilX; o.bilY = a.bilY; o.debug = a.debug;
         o.lds_cols = a.outsideCols; o.lds_rows = a.outsideRows;
         return launch_outside_staged(kTileH, in_fmt, mid_fmt, out_fmt, o, nTiles, batch, s);
     }

@@ -59,6 +59,7 @@ struct EasuArgs {
     const BilinTap *bilX;   // [outW], [outH] device tables for the bilinear fallback (product build)
     const BilinTap *bilY;
     const uint32_t *tileList; // optional: tile index of each block (mask-sorted launch); null = all tiles in XCD order
+    const uint32_t *tileRec;  // records parallel to tileList (OutsideArgs::tileRec), for the lists the staged outside kernel walks
     uint32_t debug;           // RCAS const0[3]; only read by the "final" outside kernel (tinted copy of the fused path)
     uint32_t outsideCols, outsideRows; // largest bilinear footprint of a 32x32 tile (outside_staged_kernel's LDS plane)
     float rcpOutW, rcpOutH;   // RN(1/outW), RN(1/outH): o/out as mul + 2 fma (Markstein), see div_exact
@@ -76,6 +77,9 @@ struct OutsideArgs {
     const BilinTap *bilY;
     uint32_t debug;
     uint32_t lds_cols, lds_rows; // LDS texel plane extent (set by launch_outside_staged from the tap tables' host copy)
+    const uint32_t *tileRec;     // 4 dwords per list entry (host-built, parallel to tileList): ox0 | oy0 << 16, (X0+1) | (Y0+1) << 16,
+                                 // colsN | rowsN << 8, 0 -- tile origin, footprint origin and extent (see outside_staged_kernel)
+    uint32_t nTiles;             // list length; the kernel is persistent: block b walks entries b, b + gridDim.x, ...
 };
 
 struct RcasArgs {
@@ -116,6 +120,7 @@ struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) mi
     uint32_t tilesX, tilesY;
     uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const uint32_t *tileList; // optional mask-sorted group list (see EasuArgs)
+    const uint32_t *tileRec;  // records parallel to tileList (OutsideArgs::tileRec)
     const BilinTap *bilX;     // DirectCopy taps of the mask-sorted outside kernel (see OutsideArgs)
     const BilinTap *bilY;
     uint32_t outsideCols, outsideRows; // largest bilinear footprint of a 32x24 group

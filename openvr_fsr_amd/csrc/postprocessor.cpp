@@ -96,6 +96,7 @@ void PostProcessor::Reset()
     if (bilinDev_) (void)hipFree(bilinDev_);
     if (tileListDev_) (void)hipFree(tileListDev_);
     tileListDev_ = nullptr;
+    tileRecDev_ = nullptr;
     nInside_[0] = nInside_[1] = nOutside_[0] = nOutside_[1] = nRing_[0] = nRing_[1] = 0;
     nisCoefDev_ = nullptr;
     bilinDev_ = nullptr;
@@ -256,7 +257,8 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
     if (doUpscale_) {
         // column / row taps of the bilinear fallback / NIS DirectCopy (SampleLevel at pos/outSize, 8-bit sub-texel snap): same IEEE
         // operations as fsr_device.inc's bilinear_uv / fixed8, evaluated once per column and row instead of per pixel
-        std::vector<BilinTap> taps((size_t)ow + oh + 64); // padding: kernels read whole quads / clamp-free rows
+        std::vector<BilinTap> &taps = bilinHost_;
+        taps.assign((size_t)ow + oh + 64, BilinTap{0, 0.0f}); // padding: kernels read whole quads / clamp-free rows
         auto fill = [](BilinTap *t, uint32_t outN, uint32_t inN) {
             for (uint32_t o = 0; o < outN; ++o) {
                 volatile float u = (float)o / (float)outN;
@@ -376,8 +378,31 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
         listOffRing_[eye] = lists.size(); lists.insert(lists.end(), ring[eye].begin(), ring[eye].end());
     }
     if (lists.empty()) return OVRFSR_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&tileListDev_), lists.size() * sizeof(uint32_t));
+    // One record per list entry for the persistent outside-tile kernel (outside_staged_kernel): tile origin, footprint origin
+    // (first column / row tap) and extent ([first tap, last tap + 1], what the kernel used to fetch through a chain of
+    // dependent scalar loads: tile index -> tap tables)
+    std::vector<uint32_t> recs(lists.size() * 4, 0u);
+    if (bilinHost_.size() >= (size_t)outputWidth_ + outputHeight_) {
+        const BilinTap *bx = bilinHost_.data(), *by = bilinHost_.data() + outputWidth_;
+        const uint32_t rowsCap = outsideRows_[tileH == 24 ? 1 : 0];
+        for (size_t i = 0; i < lists.size(); ++i) {
+            const uint32_t t = lists[i], tyi = t / tx, txi = t - tyi * tx;
+            const uint32_t ox0 = txi * tileW, oy0 = tyi * tileH;
+            const int X0 = bx[ox0].i0, Y0 = by[oy0].i0;
+            const int colsN = std::min<int>((int)outsideCols_, bx[std::min(ox0 + tileW - 1, outputWidth_ - 1)].i0 + 2 - X0);
+            const int rowsN = std::min<int>((int)rowsCap, by[std::min(oy0 + tileH - 1, outputHeight_ - 1)].i0 + 2 - Y0);
+            recs[4 * i + 0] = ox0 | (oy0 << 16);
+            recs[4 * i + 1] = (uint32_t)(X0 + 1) | ((uint32_t)(Y0 + 1) << 16);
+            recs[4 * i + 2] = (uint32_t)colsN | ((uint32_t)rowsN << 8);
+        }
+    }
+    const size_t listDwords = (lists.size() + 3) & ~(size_t)3; // the records follow the lists, 16-byte aligned
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&tileListDev_), (listDwords + recs.size()) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(tileListDev_, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        tileRecDev_ = tileListDev_ + listDwords;
+        e = hipMemcpy(tileRecDev_, recs.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("tile lists: ") + hipGetErrorString(e));
     return OVRFSR_OK;
 }
@@ -424,6 +449,7 @@ void PostProcessor::FillNis(NisArgs &a, int firstEye, int alternate) const
     a.kSrcNormX = c.kSrcNormX; a.kSrcNormY = c.kSrcNormY;
     a.reserved1 = c.reserved1;
     FillMask(a.m, firstEye, alternate);
+    a.tileRec = nullptr;
     a.coefScale = nisCoefDev_;
     a.coefUsm = nisCoefDev_ + 512;
     a.cellsW = nisCellsW_; a.cellsH = nisCellsH_;
@@ -483,6 +509,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
                 }
                 if (e == hipSuccess && nOutside_[ps.eye]) {
                     b.tileList = tileListDev_ + listOffOutside_[ps.eye];
+                    b.tileRec = tileRecDev_ + 4 * listOffOutside_[ps.eye];
                     e = launch_nis_outside((int)in.format, (int)out.format, b, nOutside_[ps.eye], ps.cnt, aux);
                 }
             }
@@ -511,6 +538,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
             }
             if (e == hipSuccess && nOutside_[ps.eye]) {
                 b.tileList = tileListDev_ + listOffOutside_[ps.eye];
+                b.tileRec = tileRecDev_ + 4 * listOffOutside_[ps.eye];
                 e = launch_easu_outside((int)in.format, -1, (int)out.format, b, nOutside_[ps.eye], ps.cnt, aux);
             }
         }
@@ -530,6 +558,7 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
     a.cellsW = cellsW_; a.cellsH = cellsH_;
     a.bilX = bilinDev_; a.bilY = bilinDev_ + outputWidth_;
     a.tileList = nullptr;
+    a.tileRec = nullptr;
     a.debug = rcasCon_[3];
     a.rcpOutW = rcpOut_[0]; a.rcpOutH = rcpOut_[1]; a.rcpExact = rcpExact_ ? 1u : 0u;
     a.outsideCols = outsideCols_; a.outsideRows = outsideRows_[0];
@@ -603,11 +632,13 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
         }
         if (e == hipSuccess && nOutside_[eye]) {
             eo.tileList = tileListDev_ + listOffOutside_[eye];
+            eo.tileRec = tileRecDev_ + 4 * listOffOutside_[eye];
             e = launch_easu_outside((int)in.format, (int)mid.format, (int)out.format, eo, nOutside_[eye], ps.cnt, aux);
         }
         if (e == hipSuccess && nInside_[eye]) {
             if (nRing_[eye]) {
                 em.tileList = tileListDev_ + listOffRing_[eye];
+                em.tileRec = tileRecDev_ + 4 * listOffRing_[eye];
                 e = launch_easu_outside((int)in.format, -1, (int)mid.format, em, nRing_[eye], ps.cnt, stream);
             }
             if (e == hipSuccess) {
@@ -659,6 +690,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
             }
             if (e == hipSuccess && nOutside_[ps.eye]) {
                 eb.tileList = tileListDev_ + listOffOutside_[ps.eye];
+                eb.tileRec = tileRecDev_ + 4 * listOffOutside_[ps.eye];
                 e = launch_easu_outside((int)in.format, (int)IntermediateFormat(), (int)out.format, eb, nOutside_[ps.eye], ps.cnt, aux);
             }
         }

@@ -5,6 +5,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <string>
+#include <vector>
 #include "../../include/openvr_fsr_amd.h"
 #include "fsr_params.h"
 #include "nis_tables.h"
@@ -73,6 +74,8 @@ private:
     // mask-sorted EASU tile lists (product build, masked configs): per eye, tiles with any group inside the radius
     // and tiles entirely outside; the latter run through an LDS-free kernel at twice the occupancy
     uint32_t *tileListDev_ = nullptr;
+    uint32_t *tileRecDev_ = nullptr;      // records of the same entries (inside the tileListDev_ allocation), 4 dwords each
+    std::vector<BilinTap> bilinHost_;     // host copy of the column / row tap tables (bilinDev_)
     uint32_t nInside_[2] = {0, 0}, nOutside_[2] = {0, 0}, nRing_[2] = {0, 0};
     size_t listOffInside_[2] = {0, 0}, listOffOutside_[2] = {0, 0}, listOffRing_[2] = {0, 0}; // ring: outside tiles 4-adjacent to an inside tile
     bool useSorted_ = false;   // masked EASU+RCAS: two passes on the inside list, final-form outside tiles (ApplySorted)
