@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <new>
 #include "postprocessor.hpp"
 #include "nis_tables.h"
@@ -90,11 +91,14 @@ OVRFSR_API int ovrfsr_create(int device, const ovrfsr_config *cfg, ovrfsr_ctx **
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return OVRFSR_ERR_NO_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return OVRFSR_ERR_NO_DEVICE; // kernels are gfx950-only
     return guarded([&] {
-        ovrfsr_ctx *c = new (std::nothrow) ovrfsr_ctx;
+        // owned until success: a throwing PostProcessor constructor (its std::string / std::vector members) must not leak the ctx
+        std::unique_ptr<ovrfsr_ctx> c(new (std::nothrow) ovrfsr_ctx);
         if (!c) return (int)OVRFSR_ERR_OUT_OF_MEMORY;
-        c->pp = new (std::nothrow) ovrfsr::PostProcessor(device, *cfg);
-        if (!c->pp) { delete c; return (int)OVRFSR_ERR_OUT_OF_MEMORY; }
-        *out_ctx = c;
+        c->pp = nullptr;
+        std::unique_ptr<ovrfsr::PostProcessor> pp(new (std::nothrow) ovrfsr::PostProcessor(device, *cfg));
+        if (!pp) return (int)OVRFSR_ERR_OUT_OF_MEMORY;
+        c->pp = pp.release();
+        *out_ctx = c.release();
         return (int)OVRFSR_OK;
     });
 }

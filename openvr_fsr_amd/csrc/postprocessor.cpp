@@ -775,10 +775,20 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
     if (timing) {
         (void)hipEventRecord(queries_[currentQuery_].end, stream);
         queries_[currentQuery_].pending = true;
+        queries_[currentQuery_].images = n;
         lastQuery_ = currentQuery_;
         CollectQuery(stream);
     }
     return rc;
+}
+
+// the kernels read neighbours of what other workgroups write: the byte ranges of input and output images must be disjoint
+bool PostProcessor::RangesOverlap(const ovrfsr_image &in0, size_t inStride, const ovrfsr_image &out0, size_t outStride, uint32_t n)
+{
+    const uintptr_t i0 = reinterpret_cast<uintptr_t>(in0.data), o0 = reinterpret_cast<uintptr_t>(out0.data);
+    const uintptr_t i1 = i0 + (n - 1) * inStride + (size_t)in0.pitch_bytes * in0.height;
+    const uintptr_t o1 = o0 + (n - 1) * outStride + (size_t)out0.pitch_bytes * out0.height;
+    return i0 < o1 && o0 < i1;
 }
 
 int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds, ovrfsr_image *out, hipStream_t stream)
@@ -813,6 +823,8 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
         rc = CheckImage(out, "out");
         if (rc != OVRFSR_OK) return rc;
         if (out->width != outputWidth_ || out->height != outputHeight_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "out has the wrong size");
+        // an in-place call (plausible in sharpen-only mode, where the sizes agree) would race: RCAS / NVSharpen read neighbour texels
+        if (RangesOverlap(*in, 0, *out, 0, 1)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output images overlap");
         dst = *out;
     } else {
         dst.width = outputWidth_; dst.height = outputHeight_;
@@ -854,13 +866,7 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "batch stride smaller than one image");
     if (n > 1 && (inStride % texel_bytes(in0->format) != 0 || outStride % texel_bytes(out0->format) != 0))
         return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "batch stride is not a multiple of the texel size (images i > 0 would be misaligned)");
-    {
-        // the kernels read neighbours of what other workgroups write: input and output ranges must be disjoint
-        const uintptr_t i0 = reinterpret_cast<uintptr_t>(in0->data), o0 = reinterpret_cast<uintptr_t>(out0->data);
-        const uintptr_t i1 = i0 + (n - 1) * inStride + (size_t)in0->pitch_bytes * in0->height;
-        const uintptr_t o1 = o0 + (n - 1) * outStride + (size_t)out0->pitch_bytes * out0->height;
-        if (i0 < o1 && o0 < i1) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output batches overlap");
-    }
+    if (RangesOverlap(*in0, inStride, *out0, outStride, n)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output batches overlap");
     DeviceGuard guard(device_);
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
     if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || !textureContainsOnlyOneEye_))
@@ -881,12 +887,16 @@ void PostProcessor::CollectQuery(hipStream_t stream)
     currentQuery_ = (currentQuery_ + 1) % kQueryCount;
     ProfileQuery &q = queries_[currentQuery_];
     if (!q.pending) return;
+    // no host waits while a graph is captured.  (The legacy NULL stream cannot be captured, and querying it while ANOTHER
+    // stream is in global-mode capture would invalidate that capture: skipped.)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return; // no host waits while a graph is captured
+    if (stream != nullptr && (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) return;
     float ms = 0.0f;
     if (hipEventSynchronize(q.end) != hipSuccess || hipEventElapsedTime(&ms, q.start, q.end) != hipSuccess) return; // "disjoint": reading dropped
     q.pending = false;
-    summedGpuTime_ += ms * 1e-3f;
+    // the reference times one Apply = one eye image (x2 below when each eye has its own texture: a frame); a batched apply
+    // covered q.images of them, so its reading counts per image
+    summedGpuTime_ += ms * 1e-3f / (float)(q.images ? q.images : 1u);
     if (++countedQueries_ >= 500) {
         float avgTimeMs = 1000.f / countedQueries_ * summedGpuTime_;
         if (textureContainsOnlyOneEye_) avgTimeMs *= 2;

@@ -100,7 +100,7 @@ private:
     // slot is read back (so the wait is normally over already), durations are summed and every 500 readings the mean
     // is published -- doubled when each eye has its own texture, i.e. "per frame" (PostProcessor.cpp:605-626)
     static constexpr int kQueryCount = 6;
-    struct ProfileQuery { hipEvent_t start = nullptr, end = nullptr; bool pending = false; };
+    struct ProfileQuery { hipEvent_t start = nullptr, end = nullptr; bool pending = false; uint32_t images = 1; };
     ProfileQuery queries_[kQueryCount];
     int currentQuery_ = 0, lastQuery_ = -1;
     float summedGpuTime_ = 0.0f;   // seconds
@@ -121,6 +121,7 @@ private:
     int PrepareNisResources();                                           // :307-310, :366-382, :432-435
     void FillNis(NisArgs &a, int firstEye, int alternate) const;
     int EnsureBuffer(void **buf, size_t *have, size_t need);
+    static bool RangesOverlap(const ovrfsr_image &in0, size_t inStride, const ovrfsr_image &out0, size_t outStride, uint32_t n);
     uint32_t IntermediateFormat() const;
     int ApplyPostProcess(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                          const ovrfsr_image &out, size_t outStride, hipStream_t stream); // :563-638

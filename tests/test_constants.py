@@ -127,3 +127,28 @@ def test_fixture_is_fresh_against_reference():
         f = float((rng.uniform(1, 2) * 2.0 ** rng.integers(-40, 30)) * rng.choice([-1, 1]))
         f = float(np.float32(f))
         assert O.lib().ovo_f32_to_f16_trunc(f) == R.ref_f32_to_f16(f)
+
+
+def test_unorm8_decode_two_op_form_is_correctly_rounded():
+    """fsr_device.inc unorm8_to_unit: b/255 as fma(b, k_hi, RN(b*k_lo)) with 1/255 = k_hi + k_lo (0x3b808081, 0xaf7efeff) is the
+    correctly rounded quotient for every byte -- checked here against exact rational arithmetic (the claim the kernel comment
+    makes; every RGBA8 path of both builds decodes through it)."""
+    from fractions import Fraction
+    k_hi = np.array([0x3b808081], np.uint32).view(np.float32)[0]
+    k_lo = np.array([0xaf7efeff], np.uint32).view(np.float32)[0]
+
+    def rn(fr):  # round an exact Fraction to the nearest float32 (ties to even): float64 holds fr to 2^-53, far finer than
+        return np.float32(float(fr))  # any float32 rounding boundary of these values (checked below by the margin assert)
+
+    for b in range(256):
+        lo = np.float32(np.float32(b) * k_lo)                              # RN(b * k_lo)
+        exact = Fraction(int(b)) * Fraction(float(k_hi)) + Fraction(float(lo))   # fma: one rounding of the exact sum
+        got = rn(exact)
+        want = rn(Fraction(b, 255))
+        assert got == want, (b, got, want)
+        # margin: the exact fma argument and b/255 are both far (>= 2^-40 relative) from a float32 rounding boundary
+        if b:
+            ulp = float(np.spacing(want))
+            for v in (exact, Fraction(b, 255)):
+                frac = (v - Fraction(float(want))) / Fraction(ulp)
+                assert abs(abs(frac) - Fraction(1, 2)) > Fraction(1, 2 ** 20), (b, float(frac))

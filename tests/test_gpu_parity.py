@@ -437,6 +437,23 @@ def test_disabled_and_reset_behaviour(gpu):
     pp.close()
 
 
+def test_in_place_apply_is_rejected(gpu):
+    """RCAS / NVSharpen read neighbour texels that other workgroups write: an output overlapping the input is refused by
+    ovrfsr_apply (sharpen-only, where the sizes agree and the mistake is plausible) exactly as by ovrfsr_apply_batch."""
+    import torch
+    import openvr_fsr_amd as A
+    t = torch.from_numpy(synth.random_u8(64, 48, 5)).cuda()
+    for nis in (0, 1):
+        pp = A.PostProcessor(fsr_enabled=1, use_nis=nis, render_scale=1.0, sharpness=0.9, radius=2.0)
+        with pytest.raises(A.OvrFsrError) as e:
+            pp.apply(0, t, out=t)
+        assert e.value.status == 1   # OVRFSR_ERR_INVALID_ARGUMENT
+        out = torch.empty_like(t)
+        pp.apply(0, t, out=out)      # the ctx is still usable
+        torch.cuda.synchronize()
+        pp.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # SURVEY 8(f) rank 1: fused EASU -> RCAS (intermediate in LDS) == the two-kernel path, bit for bit
 # ------------------------------------------------------------------------------------------------
