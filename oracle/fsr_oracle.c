@@ -31,7 +31,7 @@
  *
  * Pinning status: bit-exact against the reference's own FsrEasuF/FsrRcasF/FsrEasuCon/FsrRcasCon
  * compiled for the CPU through oracle/hlsl_shim.hpp (oracle/_ref, see oracle/Makefile and
- * tests/test_oracle_vs_ref.py) and against the committed vectors in tests/golden/.
+ * tests/test_oracle.py) and against the committed vectors in tests/golden/.
  */
 #include <math.h>
 #include <stdint.h>

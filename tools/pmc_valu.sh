@@ -30,7 +30,7 @@ for k, cs in agg.items():
         print("%-8s %-66s %-22s n=%3d mean per launch (8 eye images) %16.1f" % (sys.argv[2], k, c, len(v), sum(v) / len(v)))
     if "SQ_ACTIVE_INST_VALU" in cs and "GRBM_GUI_ACTIVE" in cs:
         a, g = sum(cs["SQ_ACTIVE_INST_VALU"]) / len(cs["SQ_ACTIVE_INST_VALU"]), sum(cs["GRBM_GUI_ACTIVE"]) / len(cs["GRBM_GUI_ACTIVE"])
-        print("%-8s %-66s %-22s %.3f  (4*SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))" % (sys.argv[2], k, "valu_busy", 4 * a / (g / 8 * 1024)))
+        print("%-8s %-66s %-22s %.3f  (4*SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs))" % (sys.argv[2], k, "valu_active_ratio", 4 * a / (g / 8 * 1024)))
 PY
   done
   cat "$OUT/sq_$W.txt"
