@@ -123,6 +123,9 @@ size_t fused_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
 {
     size_t e = easu_lds_bytes(prec, in_fmt, cellsW, cellsH);
     e = (e + 15) & ~(size_t)15;
+    // product build: the luma plane doubles as the near-tie list region (fused_kernel) and is at least that large
+    if (prec != PREC_FP32_STRICT && easu_fast_pitch(cellsW) != 0 && (size_t)easu_fast_pitch(cellsW) * cellsH * 4 < kFusedTieListBytes)
+        e += kFusedTieListBytes;
     return e + (size_t)(kTileW + 2) * (kTileH + 2) * 16;
 }
 

@@ -18,7 +18,8 @@ constexpr int kTileH = 32;
 constexpr int kThreads = 256;
 constexpr int kLumPadRows = 5;    // rows past the EASU luma plane that the 4-rows-per-lane analysis sweep may read (allocated, never written)
 // dynamic LDS the fused kernel may ask for: the 160 KiB of a CU minus its static LDS (the near-tie lists)
-constexpr size_t kFusedLdsMax = 156 * 1024;
+constexpr size_t kFusedLdsMax = 159 * 1024;
+constexpr size_t kFusedTieListBytes = 2560; // fused kernel: 4 waves x 5 sweeps x 64 near-tie entries (uint16), kept in the luma plane
 constexpr int kOutsidePitch = 40; // outside_staged_kernel: floats per channel row of its planar LDS texel plane (>= 36 columns)
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
 constexpr int kRcasDppTileH = 32; //                  4 waves x 8 rows per lane
@@ -64,6 +65,7 @@ struct EasuArgs {
     uint32_t outsideCols, outsideRows; // largest bilinear footprint of a 32x32 tile (outside_staged_kernel's LDS plane)
     float rcpOutW, rcpOutH;   // RN(1/outW), RN(1/outH): o/out as mul + 2 fma (Markstein), see div_exact
     uint32_t rcpExact;        // host verified that form against IEEE division for every o < outW (outH); else 0
+    float tieHalfMin;         // near-tie guard of RGBA16F stores: values below it are not guarded (see near_tie_half); +inf = off
 };
 
 // LDS-staged bilinear fallback / DirectCopy of mask-sorted tiles entirely outside the radius (product build,
@@ -103,6 +105,7 @@ struct FusedArgs {
     uint32_t tilesX, tilesY;
     uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs)
+    float tieHalfMin;         // near-tie guard of a half intermediate (see EasuArgs)
 };
 
 struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) minus the unused viewport fields

@@ -559,11 +559,27 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
     a.bilX = bilinDev_; a.bilY = bilinDev_ + outputWidth_;
     a.tileList = nullptr;
     a.tileRec = nullptr;
+    a.tieHalfMin = TieHalfMin();
     a.debug = rcasCon_[3];
     a.rcpOutW = rcpOut_[0]; a.rcpOutH = rcpOut_[1]; a.rcpExact = rcpExact_ ? 1u : 0u;
     a.outsideCols = outsideCols_; a.outsideRows = outsideRows_[0];
     a.tilesX = (out.width + kTileW - 1) / kTileW;   // the reference dispatches 16x16 groups (PostProcessor.cpp:399);
     a.tilesY = (out.height + kTileH - 1) / kTileH;  // a tile here is 2x2 of those
+}
+
+// Near-tie guard of a half-float intermediate: the smallest value whose flipped half rounding could exceed the 1e-3 tolerance
+// behind RCAS.  RCAS's gain on its centre tap is at most 1 / (1 - 4 * 0.1875 * sharp) (lobe >= -FSR_RCAS_LIMIT * sharp,
+// ffx_fsr1.h:654,757-765); a half in [b, 2b) moves in steps of b * 2^-10.  Binades whose step times that gain stays under
+// 9e-4 are left alone; +inf (guard off) when no sharpening pass follows the upscale.
+float PostProcessor::TieHalfMin() const
+{
+    if (!(doUpscale_ && doSharpen_) || cfg_.use_nis) return INFINITY;
+    float sharp;
+    std::memcpy(&sharp, &rcasCon_[0], 4);
+    const float gain = 1.0f / (1.0f - 0.75f * sharp);
+    float b = 1.0f / 16384.0f; // half's smallest normal binade
+    while (b < 65536.0f && gain * b * (1.0f / 1024.0f) < 9e-4f) b *= 2.0f;
+    return b;
 }
 
 // Mask-sorted launches use per-eye tile lists.  Both eyes share the lists when their mask centres coincide;
@@ -666,6 +682,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
     a.tilesX = (out.width + kTileW - 1) / kTileW;
     a.tilesY = (out.height + kTileH - 1) / kTileH;
     a.tileList = nullptr;
+    a.tieHalfMin = TieHalfMin();
     hipError_t e = hipSuccess;
     if (!tileListDev_) {
         e = launch_fused(cfg_.precision, (int)in.format, (int)IntermediateFormat(), (int)out.format, a, n, stream);

@@ -123,6 +123,7 @@ private:
     int EnsureBuffer(void **buf, size_t *have, size_t need);
     static bool RangesOverlap(const ovrfsr_image &in0, size_t inStride, const ovrfsr_image &out0, size_t outStride, uint32_t n);
     uint32_t IntermediateFormat() const;
+    float TieHalfMin() const;
     int ApplyPostProcess(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,
                          const ovrfsr_image &out, size_t outStride, hipStream_t stream); // :563-638
     int ApplyUpscaling(uint32_t n, int firstEye, int alternate, const ovrfsr_image &in, size_t inStride,

@@ -498,12 +498,12 @@ def test_fused_half_float_and_full_size(gpu):
     two = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5, fused=0)
     one = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5, fused=1)
     assert np.array_equal(one.view(np.uint16), two.view(np.uint16))
-    # product build: the compiler may fold an fp32 multiply into the fp32->fp16 conversion (one rounding instead of
-    # two) differently in the two kernels, so a half-float intermediate can differ by one fp16 ulp on rare ties
+    # product build: both forms guard the half intermediate's near-ties (near_tie_half), so what is left between them is
+    # the final half rounding of RCAS's output
     two = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5, fused=0).astype(np.float32)
     one = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5, fused=1).astype(np.float32)
     d = np.abs(one - two)
-    assert d.max() <= 4e-3 and (d > 0).mean() <= 1e-3, (float(d.max()), float((d > 0).mean()))
+    assert d.max() <= 1e-3 and (d > 0).mean() <= 1e-3, (float(d.max()), float((d > 0).mean()))
     iw, ih, ow, oh = 1683, 1869, 2244, 2492
     img8 = synth.structured_u8(iw, ih, synth.seed_for(1, 0))
     assert np.array_equal(run_gpu(img8, ow, oh, np.uint8, precision=STRICT, sharpness=0.9, fused=1),
@@ -576,7 +576,7 @@ def test_masked_minification_product(gpu, fused, dt):
         assert mx <= RCAS_LSB and frac <= 2 * LSB_FRACTION, (mx, frac)
     else:
         d = np.abs(got.astype(np.float32) - want.astype(np.float32))
-        assert d.max() <= 4e-3 and (d > 1e-3).mean() <= 1e-4, (float(d.max()), float((d > 1e-3).mean()))
+        assert d.max() <= 1e-3, float(d.max())
 
 
 @pytest.mark.parametrize("dtype,radius,nis", [(np.uint8, 2.0, 0), (np.uint8, 0.5, 0), (np.float16, 0.5, 0), (np.uint8, 0.5, 1)])

@@ -147,9 +147,9 @@ def test_c5_masked_half(gpu):
     r = _rec("C5", "strict", "structured", "half", run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5), want)
     assert r["n_diff"] == 0
     r = _rec("C5", "product", "structured", "half", run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5), want)
-    # a half intermediate has 2^-11 relative steps: where the product build's EASU lands on the other side of a half
-    # rounding boundary the intermediate moves by one half ulp (<= 4.9e-4 below 1.0) and RCAS amplifies it up to 4x
-    assert r["max_abs"] <= 4e-3 and r["n_gt_1e-3"] <= 1e-5 * r["n_total"], r
+    # the half intermediate's near-ties are re-resolved in the reference's operator order wherever a flipped half-ulp could
+    # exceed the tolerance behind RCAS's gain (near_tie_half): north_star's bound holds on every value
+    assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
 
 
 @pytest.mark.parametrize("content", ["structured", "random"])
