@@ -226,7 +226,7 @@ hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt
     if (a.lds_cols < 2 || a.lds_cols > 36 || a.lds_rows < 2 || a.lds_rows > 34) return hipErrorInvalidValue;
     // persistent workgroups: block b walks list entries b, b + G, ... (G a multiple of 8: the list is XCD-banded, entry e
     // belongs to band e % 8, so a workgroup stays in its XCD's band); OVRFSR_OUTSIDE_TPW = tiles per workgroup (tuning)
-    static const uint32_t tpw = [] { const char *e = std::getenv("OVRFSR_OUTSIDE_TPW"); const int v = e ? std::atoi(e) : 6; return (uint32_t)(v < 1 ? 1 : v); }();
+    static const uint32_t tpw = [] { const char *e = std::getenv("OVRFSR_OUTSIDE_TPW"); const int v = e ? std::atoi(e) : 2; return (uint32_t)(v < 1 ? 1 : v); }();
     a.nTiles = nTiles;
     uint32_t G = ((nTiles + tpw - 1) / tpw + 7u) & ~7u;
     if (G > nTiles) G = nTiles;

@@ -372,10 +372,12 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
     for (int eye = 0; eye < 2; ++eye) {
         xcd_order(in[eye]); xcd_order(outl[eye]);
         nInside_[eye] = (uint32_t)in[eye].size(); nOutside_[eye] = (uint32_t)outl[eye].size();
+        // inside | ring | outside: the ring tiles follow the inside tiles so that ONE EASU launch over nInside + nRing entries
+        // also writes the bilinear intermediate of the ring (its all-outside path), while RCAS walks the first nInside only
         listOffInside_[eye] = lists.size(); lists.insert(lists.end(), in[eye].begin(), in[eye].end());
-        listOffOutside_[eye] = lists.size(); lists.insert(lists.end(), outl[eye].begin(), outl[eye].end());
         nRing_[eye] = (uint32_t)ring[eye].size();
         listOffRing_[eye] = lists.size(); lists.insert(lists.end(), ring[eye].begin(), ring[eye].end());
+        listOffOutside_[eye] = lists.size(); lists.insert(lists.end(), outl[eye].begin(), outl[eye].end());
     }
     if (lists.empty()) return OVRFSR_OK;
     // One record per list entry for the persistent outside-tile kernel (outside_staged_kernel): tile origin, footprint origin
@@ -641,10 +643,13 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
             em.m.alternate = eo.m.alternate = rb.m.alternate = 0;
         }
         const int eye = ps.eye;
-        // launch order matters for how the two hardware queues share the chip: the VALU-bound kernel first
+        // launch order matters for how the two hardware queues share the chip: the VALU-bound kernel first.  The EASU launch
+        // covers the inside tiles AND the ring (outside tiles 4-adjacent to them, listed right behind: RCAS taps reach one
+        // pixel across a tile edge); its all-outside path writes their bilinear intermediate, the same bytes the separate
+        // ring launch of rounds 1-2 wrote
         if (nInside_[eye]) {
             em.tileList = tileListDev_ + listOffInside_[eye];
-            e = launch_easu(cfg_.precision, (int)in.format, (int)mid.format, em, ps.cnt, stream, nInside_[eye]);
+            e = launch_easu(cfg_.precision, (int)in.format, (int)mid.format, em, ps.cnt, stream, nInside_[eye] + nRing_[eye]);
         }
         if (e == hipSuccess && nOutside_[eye]) {
             eo.tileList = tileListDev_ + listOffOutside_[eye];
@@ -652,15 +657,8 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
             e = launch_easu_outside((int)in.format, (int)mid.format, (int)out.format, eo, nOutside_[eye], ps.cnt, aux);
         }
         if (e == hipSuccess && nInside_[eye]) {
-            if (nRing_[eye]) {
-                em.tileList = tileListDev_ + listOffRing_[eye];
-                em.tileRec = tileRecDev_ + 4 * listOffRing_[eye];
-                e = launch_easu_outside((int)in.format, -1, (int)mid.format, em, nRing_[eye], ps.cnt, stream);
-            }
-            if (e == hipSuccess) {
-                rb.tileList = tileListDev_ + listOffInside_[eye];
-                e = launch_rcas(cfg_.precision, (int)mid.format, (int)out.format, rb, ps.cnt, stream, nInside_[eye]);
-            }
+            rb.tileList = tileListDev_ + listOffInside_[eye];
+            e = launch_rcas(cfg_.precision, (int)mid.format, (int)out.format, rb, ps.cnt, stream, nInside_[eye]);
         }
     }
     Join(stream);
