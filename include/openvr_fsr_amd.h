@@ -65,13 +65,17 @@ typedef enum ovrfsr_format {
 
 /* Arithmetic the kernels run in.  The reference only ever compiles the fp32 bodies
  * (`//#define A_HALF`, src/fsr/fsr_easu.hlsl:3).
- *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp): the product build
+ *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp): the product build.  Its quantised EASU stores
+ *                (the UNORM8 / half intermediate, an EASU-only UNORM8 output) are nevertheless the STRICT build's, bit for bit:
+ *                pixels whose result lies within 2^-9 byte (2^-17 for half) of a rounding boundary are re-resolved in the
+ *                reference's operator order (near-tie guard); float outputs differ by <= 3e-6, UNORM8 pipeline
+ *                outputs by <= 1 LSB
  *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
  *                to the CPU oracle; a validation build, not a fast one
  * There is no packed-half arithmetic mode (value 1 was reserved for one in ABI 1 and is rejected with
  * OVRFSR_ERR_INVALID_ARGUMENT by ovrfsr_create / ovrfsr_set_config): on gfx950 v_pk_*_f16 issues at the rate of
  * v_pk_*_f32 (profiles/r02_valu_issue_rates.txt), the fp32 kernels already process two taps per packed instruction, and
- * half accumulation of 12 taps misses the 1e-3 tolerance -- the "fp16" of BASELINE configs C2/C3/C5 is served by fp32
+ * half accumulation of 12 taps misses the 1e-3 tolerance (measured: 3.9e-3, profiles/r03_half_acc.txt) -- the "fp16" of BASELINE configs C2/C3/C5 is served by fp32
  * arithmetic with RGBA16F images and a half intermediate where the config asks for packed-half I/O. */
 typedef enum ovrfsr_precision {
     OVRFSR_PRECISION_FP32 = 0,
@@ -156,7 +160,8 @@ OVRFSR_API int ovrfsr_output_size(const ovrfsr_config *cfg, uint32_t in_width, u
  *           -- the reference's behaviour of swapping Texture_t::handle for its own texture
  *           (PostProcessor.cpp:161), valid until the next apply on this ctx.  If out->data is set
  *           the result is written there (width/height must equal the output size; format
- *           selects the store conversion).  When the ctx is a pass-through (fsr disabled, or the
+ *           selects the store conversion; its bytes must not overlap the input image's: the sharpen
+ *           stages read neighbour texels other workgroups write -- OVRFSR_ERR_INVALID_ARGUMENT).  When the ctx is a pass-through (fsr disabled, or the
  *           second Submit of a shared texture, PostProcessor.cpp:155-158) *out describes the
  *           image the compositor should receive and nothing is launched.
  *   stream  hipStream_t (NULL = default stream).  Launches are asynchronous on it.  A ctx owns scratch device
