@@ -28,7 +28,7 @@ extern "C" {
 #define OVRFSR_API
 #endif
 
-#define OVRFSR_ABI_VERSION 2u /* 2: ovrfsr_average_gpu_time_ms added; precision value 1 (never built) removed */
+#define OVRFSR_ABI_VERSION 3u /* 3: ovrfsr_apply_batch_shared added.  2: ovrfsr_average_gpu_time_ms added; precision value 1 (never built) removed */
 
 typedef enum ovrfsr_status {
     OVRFSR_OK = 0,
@@ -177,10 +177,17 @@ OVRFSR_API int ovrfsr_apply(ovrfsr_ctx *ctx, int eye, const ovrfsr_image *in, co
 /* Batch form for headless throughput: n eye images of identical shape, image i at
  * base + i*stride_bytes, one launch over the whole batch.  Eye of image i is
  * first_eye ^ (alternate_eyes ? (i & 1) : 0): a batch of stereo pairs is laid out L,R,L,R,...
- * Each image is its own texture (textureContainsOnlyOneEye), outputs are caller-owned. */
+ * Each image is its own texture (textureContainsOnlyOneEye), outputs are caller-owned and must not overlap the inputs. */
 OVRFSR_API int ovrfsr_apply_batch(ovrfsr_ctx *ctx, uint32_t n, int first_eye, int alternate_eyes,
                                   const ovrfsr_image *in0, size_t in_stride_bytes,
                                   const ovrfsr_image *out0, size_t out_stride_bytes, void *stream);
+
+/* The same for SHARED side-by-side textures -- one image holds both eyes, what games that submit a single texture with
+ * half-width bounds do (|uMax-uMin| <= 0.5, PostProcessor.cpp:146): every image is processed once with the two mask
+ * centres of the shared layout (imageCentre of the left eye and width/2 * (1 + projX_R) for the right one,
+ * PostProcessor.cpp:155-158,298-301), exactly as the first ovrfsr_apply of such a texture does. */
+OVRFSR_API int ovrfsr_apply_batch_shared(ovrfsr_ctx *ctx, uint32_t n, const ovrfsr_image *in0, size_t in_stride_bytes,
+                                         const ovrfsr_image *out0, size_t out_stride_bytes, void *stream);
 
 OVRFSR_API const char *ovrfsr_last_error(const ovrfsr_ctx *ctx);
 

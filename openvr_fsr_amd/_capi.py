@@ -86,6 +86,7 @@ def library():
     L.ovrfsr_apply.argtypes = [C.c_void_p, C.c_int, C.POINTER(Image), C.POINTER(Bounds), C.POINTER(Image), C.c_void_p]
     L.ovrfsr_apply_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(Image), C.c_size_t,
                                      C.POINTER(Image), C.c_size_t, C.c_void_p]
+    L.ovrfsr_apply_batch_shared.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Image), C.c_size_t, C.POINTER(Image), C.c_size_t, C.c_void_p]
     L.ovrfsr_last_error.argtypes = [C.c_void_p]
     L.ovrfsr_last_error.restype = C.c_char_p
     L.ovrfsr_last_gpu_time_ms.argtypes = [C.c_void_p, f32p]
@@ -102,7 +103,7 @@ def library():
     L.ovrfsr_nis_coef_usm.restype = f32p
     L.ovrfsr_config_from_json.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Config)]
     L.ovrfsr_save_ppm.argtypes = [C.POINTER(Image), C.c_char_p, C.c_void_p]
-    if L.ovrfsr_abi_version() != 2:
+    if L.ovrfsr_abi_version() != 3:
         raise OvrFsrError(1, "ABI version mismatch")
     _LIB = L
     return L

@@ -145,6 +145,15 @@ OVRFSR_API int ovrfsr_apply_batch(ovrfsr_ctx *ctx, uint32_t n, int first_eye, in
     });
 }
 
+OVRFSR_API int ovrfsr_apply_batch_shared(ovrfsr_ctx *ctx, uint32_t n, const ovrfsr_image *in0, size_t in_stride_bytes,
+                                         const ovrfsr_image *out0, size_t out_stride_bytes, void *stream)
+{
+    if (!ctx) return OVRFSR_ERR_INVALID_ARGUMENT;
+    return guarded([&] {
+        return ctx->pp->ApplyBatch(n, OVRFSR_EYE_LEFT, 0, in0, in_stride_bytes, out0, out_stride_bytes, static_cast<hipStream_t>(stream), true);
+    });
+}
+
 OVRFSR_API const char *ovrfsr_last_error(const ovrfsr_ctx *ctx) { return ctx ? ctx->pp->LastError() : "null ctx"; }
 
 OVRFSR_API int ovrfsr_last_gpu_time_ms(ovrfsr_ctx *ctx, float *ms)

@@ -867,7 +867,7 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
 }
 
 int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovrfsr_image *in0, size_t inStride,
-                              const ovrfsr_image *out0, size_t outStride, hipStream_t stream)
+                              const ovrfsr_image *out0, size_t outStride, hipStream_t stream, bool sharedTextures)
 {
     if (!enabled_) return Fail(OVRFSR_ERR_DISABLED, "post-processing disabled after an earlier failure; call reset");
     if (n == 0) return OVRFSR_OK;
@@ -884,10 +884,11 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     if (RangesOverlap(*in0, inStride, *out0, outStride, n)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output batches overlap");
     DeviceGuard guard(device_);
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
-    if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || !textureContainsOnlyOneEye_))
+    // shared side-by-side textures: both mask centres per image, processed once each (PostProcessor.cpp:146,155-158,298-301)
+    if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || textureContainsOnlyOneEye_ == sharedTextures))
         Reset();
     if (!initialized_) {
-        textureContainsOnlyOneEye_ = true;
+        textureContainsOnlyOneEye_ = !sharedTextures;
         rc = PrepareResources(*in0);
         if (rc != OVRFSR_OK) { enabled_ = false; return rc; }
     }

@@ -27,7 +27,7 @@ public:
     // PostProcessor::Apply, PostProcessor.cpp:123-164
     int Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds, ovrfsr_image *out, hipStream_t stream);
     int ApplyBatch(uint32_t n, int firstEye, int alternate, const ovrfsr_image *in0, size_t inStride,
-                   const ovrfsr_image *out0, size_t outStride, hipStream_t stream);
+                   const ovrfsr_image *out0, size_t outStride, hipStream_t stream, bool sharedTextures = false);
     // PostProcessor::Reset, PostProcessor.cpp:166-194
     void Reset();
     int SetConfig(const ovrfsr_config &cfg);

@@ -85,12 +85,17 @@ class PostProcessor:
             return tex  # pass-through (fsr disabled)
         return _wrap(oimg, tex.device)
 
-    def apply_batch(self, texs, outs, first_eye=K.EYE_LEFT, alternate_eyes=True, in_format=None):
-        """texs: [N, H, W, 4], outs: [N, outH, outW, 4] (image i = eye first_eye ^ (i & alternate))."""
+    def apply_batch(self, texs, outs, first_eye=K.EYE_LEFT, alternate_eyes=True, in_format=None, shared=False):
+        """texs: [N, H, W, 4], outs: [N, outH, outW, 4] (image i = eye first_eye ^ (i & alternate)); shared=True: every image is a
+        side-by-side texture holding both eyes (ovrfsr_apply_batch_shared)."""
         n = texs.shape[0]
         if outs.shape[0] != n:
             raise ValueError("outs holds %d images for a batch of %d" % (outs.shape[0], n))
         i0, o0 = image_of(texs[0], in_format), image_of(outs[0])
+        if shared:
+            self._check(self._lib.ovrfsr_apply_batch_shared(self._ctx, n, C.byref(i0), texs.stride(0) * texs.element_size(), C.byref(o0),
+                                                            outs.stride(0) * outs.element_size(), self._stream()))
+            return outs
         self._check(self._lib.ovrfsr_apply_batch(self._ctx, n, int(first_eye), int(bool(alternate_eyes)), C.byref(i0),
                                                  texs.stride(0) * texs.element_size(), C.byref(o0),
                                                  outs.stride(0) * outs.element_size(), self._stream()))

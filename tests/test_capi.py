@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     L = A.library()
-    assert L.ovrfsr_abi_version() == 2
+    assert L.ovrfsr_abi_version() == 3
     cfg = A.Config.default()
     assert cfg.struct_size == C.sizeof(A.Config) == 80
     assert C.sizeof(A.Image) == 24 and C.sizeof(A.Bounds) == 16

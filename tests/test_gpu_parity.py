@@ -414,6 +414,38 @@ def test_shared_side_by_side_texture(gpu):
     pp.close()
 
 
+def test_shared_texture_batch(gpu):
+    """ovrfsr_apply_batch_shared: n side-by-side textures (both eyes each) in one launch == the oracle's shared-texture pipeline
+    per image, strict bit-exact and product within 1 LSB, masked (two centres per image) and with a tile list."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 240, 100, 320, 133
+    proj = (0.42, 0.55, 0.61, 0.47)
+    imgs = np.stack([synth.structured_u8(iw, ih, 20 + i) for i in range(3)])
+    want = [O.fsr_pipeline_u8(imgs[i], ow, oh, sharpness=0.8, radius=0.7, proj=proj, one_eye_per_texture=False, eye=0) for i in range(3)]
+    for prec in (STRICT, FP32):
+        pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.8, radius=0.7, proj_centre=proj, precision=prec)
+        t = torch.from_numpy(imgs).cuda()
+        outs = torch.empty((3, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        pp.apply_batch(t, outs, shared=True)
+        torch.cuda.synchronize()
+        got = outs.cpu().numpy()
+        for i in range(3):
+            if prec == STRICT:
+                assert np.array_equal(got[i], want[i]), i
+            else:
+                mx, frac = lsb_stats(got[i], want[i])
+                assert mx <= RCAS_LSB and frac <= LSB_FRACTION, (i, mx, frac)
+        # the one-eye-per-texture batch form on the same ctx afterwards: the ctx rebuilds its mask constants
+        single = torch.empty((1, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        pp.apply_batch(t[:1], single, first_eye=A.EYE_RIGHT, alternate_eyes=False)
+        torch.cuda.synchronize()
+        w1 = O.fsr_pipeline_u8(imgs[0], ow, oh, sharpness=0.8, radius=0.7, proj=proj, one_eye_per_texture=True, eye=1)
+        mx, frac = lsb_stats(single.cpu().numpy()[0], w1)
+        assert mx <= (0 if prec == STRICT else RCAS_LSB), (mx, frac)
+        pp.close()
+
+
 def test_disabled_and_reset_behaviour(gpu):
     import torch
     import openvr_fsr_amd as A
