@@ -667,6 +667,24 @@ def test_plain_c_caller(gpu, tmp_path):
     assert px.std() > 10    # an image, not a constant
 
 
+def test_c_node_driver(gpu):
+    """examples/bench_node (C11 + pthreads, built by __graft_entry__.build()): the multi-GPU loop of bench.py with no Python in
+    it -- two shards (one thread, ctx and stream each; both on device 0 here: --oversubscribe), exactly K timed steps each, one
+    JSON line with per-device times."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "bench_node")
+    if not os.path.exists(exe):
+        pytest.skip("examples/bench_node not built")
+    r = subprocess.run([exe, "--gpus", "2", "--oversubscribe", "--pairs", "2", "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "eye-pairs/s" and d["value"] > 0
+    assert len(d["config"]["per_device_ms_per_step"]) == 2 and all(m > 0 for m in d["config"]["per_device_ms_per_step"])
+    assert d["config"]["pairs_per_gpu_per_step"] == 2 and "oversubscribed" in d["config"]
+
+
 # ------------------------------------------------------------------------------------------------
 # round 2: the reference's averaged GPU-time log, and the two product RCAS kernels agree byte for byte
 # ------------------------------------------------------------------------------------------------
