@@ -152,3 +152,39 @@ def test_unorm8_decode_two_op_form_is_correctly_rounded():
             for v in (exact, Fraction(b, 255)):
                 frac = (v - Fraction(float(want))) / Fraction(ulp)
                 assert abs(abs(frac) - Fraction(1, 2)) > Fraction(1, 2 ** 20), (b, float(frac))
+
+
+def test_near_tie_band_formulas():
+    """The near-tie guard's band tests (fsr_device.inc: near_tie_byte, near_tie_half), restated in numpy float32 arithmetic
+    and checked against the plain definition: a byte-domain value v is flagged iff frac(v) lies within 2^-9 of 0.5; a unit-domain
+    value x >= xmin is flagged iff it lies within 2^-17 of the midpoint of two neighbouring half values.  (The device functions
+    are these expressions; the GPU tests prove their effect -- n_diff == 0 -- this pins the band they implement.)"""
+    K = 9
+    rng = np.random.default_rng(5)
+    v = np.concatenate([rng.uniform(0, 255, 200000), np.arange(0, 255)[:, None].repeat(64, 1).ravel() + 0.5 + rng.uniform(-2.0 ** -7, 2.0 ** -7, 255 * 64)]).astype(np.float32)
+    bias = np.float32(256.0 + 2.0 ** -K)
+    mask = np.uint32(((1 << (K - 1)) - 1) << (16 - K))
+    flagged = ((v + bias).astype(np.float32).view(np.uint32) & mask) == np.uint32(0x4000)
+    dist = np.abs((v.astype(np.float64) % 1.0) - 0.5)
+    ulp = 2.0 ** -15   # v + 256 is rounded to multiples of 2^-15: the band edge is that sharp
+    assert flagged[dist < 2.0 ** -K - ulp].all()
+    assert not flagged[dist > 2.0 ** -K + ulp].any()
+    assert 0.9 * 2.0 ** (1 - K) < flagged[:200000].mean() < 1.1 * 2.0 ** (1 - K)   # 2^(1-K) of uniformly distributed values
+
+    band = np.float32(2.0 ** -17)
+    x = np.concatenate([rng.uniform(0.02, 1.9, 200000), np.float32(0.5) - rng.uniform(0, 3e-4, 2000), np.float32(1.0) - rng.uniform(0, 6e-4, 2000)]).astype(np.float32)
+    back = x.astype(np.float16).astype(np.float32)
+    half_step = ((x.view(np.uint32) & np.uint32(0x7f800000)) - np.uint32(11 << 23)).view(np.float32)
+    for xmin in (np.float32(0.25), np.float32(0.5)):
+        flagged = ((np.abs(x - back) + band).astype(np.float32) > half_step) & (x >= xmin)
+        # definition: distance of x to the nearest midpoint between consecutive half values
+        lo = np.minimum(back, x.astype(np.float64))
+        h16 = back.astype(np.float16)
+        up = np.nextafter(h16, np.float16(np.inf)).astype(np.float64)
+        dn = np.nextafter(h16, np.float16(-np.inf)).astype(np.float64)
+        mid = np.where(x.astype(np.float64) >= back, (back + up) / 2, (back + dn) / 2)
+        d = np.abs(x.astype(np.float64) - mid)
+        sel = x >= xmin
+        assert flagged[sel & (d < float(band) * 0.999)].all()
+        assert not flagged[sel & (d > float(band) * 1.001 + 1e-9)].any()
+        assert not flagged[~sel].any()
