@@ -140,13 +140,13 @@ static hipError_t fused_go3(bool strict, const FusedArgs &a, dim3 grid, size_t l
         if (once != hipSuccess) return once;
         hipLaunchKernelGGL((ovrfsr_strict::fused_kernel<I, M, O, 0>), grid, dim3(kThreads), lds, s, a);
     } else if (pitch == 32) {
-        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 32>));
+        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>));
         if (once != hipSuccess) return once;
-        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32>), grid, dim3(kThreads), lds, s, a);
+        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, a);
     } else if (pitch == 40) {
-        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 40>));
+        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>));
         if (once != hipSuccess) return once;
-        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40>), grid, dim3(kThreads), lds, s, a);
+        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, a);
     } else {
         return hipErrorInvalidValue;
     }

@@ -19,7 +19,12 @@ constexpr int kThreads = 256;
 constexpr int kLumPadRows = 5;    // rows past the EASU luma plane that the 4-rows-per-lane analysis sweep may read (allocated, never written)
 // dynamic LDS the fused kernel may ask for: the 160 KiB of a CU minus its static LDS (the near-tie lists)
 constexpr size_t kFusedLdsMax = 159 * 1024;
-constexpr size_t kFusedTieListBytes = 2560; // fused kernel: 4 waves x 5 sweeps x 64 near-tie entries (uint16), kept in the luma plane
+#ifndef OVRFSR_FUSED_NT
+#define OVRFSR_FUSED_NT 256
+#endif
+constexpr int kFusedThreads = OVRFSR_FUSED_NT; // threads per workgroup of the product build's fused kernel (one 32x32 tile either way)
+// fused kernel: waves x sweeps x 64 near-tie entries (uint16), kept in the luma plane
+constexpr size_t kFusedTieListBytes = (size_t)(kFusedThreads / 64) * (((kTileW + 2) * (kTileH + 2) + kFusedThreads - 1) / kFusedThreads) * 64 * 2;
 constexpr int kOutsidePitch = 40; // outside_staged_kernel: floats per channel row of its planar LDS texel plane (>= 36 columns)
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
 constexpr int kRcasDppTileH = 32; //                  4 waves x 8 rows per lane
