@@ -74,6 +74,9 @@ static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t
         if (dpp && unmasked) {
             const uint32_t tx = (uint32_t)(a.v.outW + kRcasDppTileW - 1) / kRcasDppTileW, ty = (uint32_t)(a.v.outH + kRcasDppTileH - 1) / kRcasDppTileH;
             hipLaunchKernelGGL((ovrfsr_fast::rcas_dpp_kernel<O>), dim3(tx * ty, 1, grid.z), dim3(kThreads), 0, s, a);
+        } else if (dpp && a.tileList && a.spanRec && a.nSpans) {
+            // mask-sorted form: the DPP kernel on 62-column segments of the runs of tiles touching the radius
+            hipLaunchKernelGGL((ovrfsr_fast::rcas_dpp_kernel<O, true>), dim3(a.nSpans, 1, grid.z), dim3(kThreads), 0, s, a);
         } else {
             hipLaunchKernelGGL((ovrfsr_fast::rcas_direct_kernel<I, O>), grid, dim3(kThreads), 0, s, a);
         }

@@ -98,6 +98,10 @@ struct RcasArgs {
     uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs); product build only
     uint32_t dppTilesXMagic;  // div_magic of rcas_dpp_kernel's own tile count per row (62-pixel tiles)
+    // masked RGBA8 pipelines (mask-sorted form): 62-column segments of the runs of tiles touching the radius, two dwords each
+    // (x0 | tileY << 16, xEnd), built by the host next to the tile lists; nSpans = 0: walk tileList with rcas_direct_kernel
+    const uint32_t *spanRec;
+    uint32_t nSpans;
 };
 
 struct FusedArgs {

@@ -97,6 +97,8 @@ void PostProcessor::Reset()
     if (tileListDev_) (void)hipFree(tileListDev_);
     tileListDev_ = nullptr;
     tileRecDev_ = nullptr;
+    spanRecDev_ = nullptr;
+    nSpans_[0] = nSpans_[1] = 0;
     nInside_[0] = nInside_[1] = nOutside_[0] = nOutside_[1] = nRing_[0] = nRing_[1] = 0;
     nisCoefDev_ = nullptr;
     bilinDev_ = nullptr;
@@ -362,6 +364,27 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
         }
     }
     listsShared_ = in[0] == in[1];
+    // RCAS on the mask-sorted form (RGBA8): per 32-row band, runs of adjacent tiles touching the radius, cut into the DPP
+    // kernel's 62-column segments (rcas_dpp_kernel<.., true>): {x0 | tileY << 16, xEnd}
+    std::vector<uint32_t> spans;
+    nSpans_[0] = nSpans_[1] = 0;
+    if (tileW == kTileW && tileH == kRcasDppTileH && outputWidth_ < 65536u && ty < 65536u) {
+        for (int eye = 0; eye < 2; ++eye) {
+            spanOff_[eye] = spans.size() / 2;
+            for (size_t i = 0; i < in[eye].size();) { // in[] is row-major here
+                size_t j = i;
+                while (j + 1 < in[eye].size() && in[eye][j + 1] == in[eye][j] + 1 && (in[eye][j + 1] / tx) == (in[eye][i] / tx)) ++j;
+                const uint32_t tyi = in[eye][i] / tx, xa = (in[eye][i] - tyi * tx) * tileW;
+                const uint32_t xb = std::min((in[eye][j] - tyi * tx + 1) * tileW, outputWidth_);
+                for (uint32_t x0 = xa; x0 < xb; x0 += kRcasDppTileW) {
+                    spans.push_back(x0 | (tyi << 16));
+                    spans.push_back(std::min(x0 + (uint32_t)kRcasDppTileW, xb));
+                }
+                i = j + 1;
+            }
+            nSpans_[eye] = (uint32_t)(spans.size() / 2 - spanOff_[eye]);
+        }
+    }
     // block b of a launch goes to XCD b % 8: hand every XCD a contiguous run of the (row-major) list
     auto xcd_order = [](std::vector<uint32_t> &v) {
         const uint32_t n = (uint32_t)v.size(), full = n & ~7u;
@@ -399,11 +422,15 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
         }
     }
     const size_t listDwords = (lists.size() + 3) & ~(size_t)3; // the records follow the lists, 16-byte aligned
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&tileListDev_), (listDwords + recs.size()) * sizeof(uint32_t));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&tileListDev_), (listDwords + recs.size() + spans.size()) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(tileListDev_, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         tileRecDev_ = tileListDev_ + listDwords;
         e = hipMemcpy(tileRecDev_, recs.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && !spans.empty()) {
+        spanRecDev_ = tileRecDev_ + recs.size();
+        e = hipMemcpy(spanRecDev_, spans.data(), spans.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("tile lists: ") + hipGetErrorString(e));
     return OVRFSR_OK;
@@ -624,6 +651,7 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
     FillMask(ra.m, firstEye, alternate);
     ra.tilesX = toOut.tilesX; ra.tilesY = toOut.tilesY;
     ra.tileList = nullptr;
+    ra.spanRec = nullptr; ra.nSpans = 0;
 
     EyePass passes[2], midPasses[2];
     const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
@@ -658,6 +686,7 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
         }
         if (e == hipSuccess && nInside_[eye]) {
             rb.tileList = tileListDev_ + listOffInside_[eye];
+            if (spanRecDev_ && nSpans_[eye]) { rb.spanRec = spanRecDev_ + 2 * spanOff_[eye]; rb.nSpans = nSpans_[eye]; }
             e = launch_rcas(cfg_.precision, (int)mid.format, (int)out.format, rb, ps.cnt, stream, nInside_[eye]);
         }
     }
@@ -737,6 +766,7 @@ int PostProcessor::ApplySharpening(uint32_t n, int firstEye, int alternate, cons
     a.tilesX = (out.width + kTileW - 1) / kTileW;
     a.tilesY = (out.height + kTileH - 1) / kTileH;
     a.tileList = nullptr;
+    a.spanRec = nullptr; a.nSpans = 0;
     hipError_t e = launch_rcas(cfg_.precision, (int)in.format, (int)out.format, a, n, stream);
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("RCAS launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;

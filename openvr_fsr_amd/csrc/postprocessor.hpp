@@ -75,6 +75,9 @@ private:
     // and tiles entirely outside; the latter run through an LDS-free kernel at twice the occupancy
     uint32_t *tileListDev_ = nullptr;
     uint32_t *tileRecDev_ = nullptr;      // records of the same entries (inside the tileListDev_ allocation), 4 dwords each
+    uint32_t *spanRecDev_ = nullptr;      // RCAS segments of the inside runs (inside the tileListDev_ allocation), 2 dwords each
+    uint32_t nSpans_[2] = {0, 0};
+    size_t spanOff_[2] = {0, 0};          // first segment of each eye (in segments)
     std::vector<BilinTap> bilinHost_;     // host copy of the column / row tap tables (bilinDev_)
     uint32_t nInside_[2] = {0, 0}, nOutside_[2] = {0, 0}, nRing_[2] = {0, 0};
     size_t listOffInside_[2] = {0, 0}, listOffOutside_[2] = {0, 0}, listOffRing_[2] = {0, 0}; // ring: outside tiles 4-adjacent to an inside tile
