@@ -713,8 +713,9 @@ def test_average_gpu_time_ring(gpu):
 
 def test_rcas_dpp_kernel_equals_per_lane_loads_kernel(gpu):
     """rcas_dpp_kernel (side taps from neighbour lanes) and rcas_direct_kernel (every lane loads its own 14 taps) are the same
-    arithmetic: identical bytes, including image borders and widths that are not a multiple of the 62-column wave tile.
-    OVRFSR_RCAS_DPP is read once per process, so each form runs in its own interpreter."""
+    arithmetic: identical bytes, including image borders and widths that are not a multiple of the 62-column wave tile -- on
+    unmasked frames (regular 62 x 32 grid) and on the mask-sorted form of masked ones (segments of the inside runs, tinted copy
+    in the groups outside the radius).  OVRFSR_RCAS_DPP is read once per process, so each form runs in its own interpreter."""
     import hashlib
     import os
     import subprocess
@@ -726,6 +727,12 @@ def test_rcas_dpp_kernel_equals_per_lane_loads_kernel(gpu):
             "for (w, hgt, gen) in [(2244, 2492, synth.structured_u8), (125, 67, synth.random_u8), (61, 33, synth.extremes_u8), (63, 5, synth.random_u8)]:\n"
             "    h.update(run_gpu(gen(w, hgt, 5), w, hgt, np.uint8, render_scale=1.0, sharpness=0.9, radius=100.0).tobytes())\n"
             "    h.update(run_gpu(gen(w, hgt, 6), w, hgt, np.float32, render_scale=1.0, sharpness=0.3, radius=100.0).tobytes())\n"
+            "# masked EASU+RCAS (mask-sorted form): rcas_dpp_kernel on 62-column segments of the inside runs vs rcas_direct_kernel on the tile list\n"
+            "for (iw, ih, ow, oh, kw) in [(300, 260, 400, 347, dict(radius=0.5)), (250, 200, 333, 267, dict(radius=0.7, debug_mode=1, proj_centre=(0.4, 0.45, 0.6, 0.55))),\n"
+            "                             (96, 80, 128, 107, dict(radius=0.3)), (1683, 1869, 2244, 2492, dict(radius=0.5)), (47, 300, 63, 400, dict(radius=1.2))]:\n"
+            "    for dt in (np.uint8, np.float32):\n"
+            "        for eye in (0, 1):\n"
+            "            h.update(run_gpu(synth.structured_u8(iw, ih, 7 + eye), ow, oh, dt, eye=eye, out_width=ow, out_height=oh, sharpness=0.9, **kw).tobytes())\n"
             "print(h.hexdigest())\n") % root
     digests = []
     for dpp in ("1", "0"):
