@@ -589,6 +589,7 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
     a.tileList = nullptr;
     a.tileRec = nullptr;
     a.tieHalfMin = TieHalfMin();
+    a.ringStrips = 0;
     a.debug = rcasCon_[3];
     a.rcpOutW = rcpOut_[0]; a.rcpOutH = rcpOut_[1]; a.rcpExact = rcpExact_ ? 1u : 0u;
     a.outsideCols = outsideCols_; a.outsideRows = outsideRows_[0];
@@ -677,6 +678,7 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
         // ring launch of rounds 1-2 wrote
         if (nInside_[eye]) {
             em.tileList = tileListDev_ + listOffInside_[eye];
+            em.ringStrips = 1; // of a ring tile, RCAS only reads the pixels next to an inside tile
             e = launch_easu(cfg_.precision, (int)in.format, (int)mid.format, em, ps.cnt, stream, nInside_[eye] + nRing_[eye]);
         }
         if (e == hipSuccess && nOutside_[eye]) {
