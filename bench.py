@@ -299,7 +299,9 @@ def dominant_kernels(workload):
     if use_nis:   # NVScaler (+ the DirectCopy kernel of the groups outside the radius, concurrent)
         return ["nis_scaler_kernel"] + ((["outside_staged_kernel"] if rgba8 else ["nis_outside_kernel"]) if radius < 2.0 else [])
     if radius < 2.0:  # tiles touching the radius: EASU+RCAS (RGBA8) or the fused kernel; the rest in final form, concurrent
-        return ["easu_fast_kernel", "rcas_direct_kernel", "outside_staged_kernel"] if rgba8 else ["fused_kernel", "easu_outside_kernel"]
+        # (RCAS of the mask-sorted form: rcas_dpp_kernel on segments of the inside runs; rcas_direct_kernel under OVRFSR_RCAS_DPP=0)
+        rcas = "rcas_direct_kernel" if os.environ.get("OVRFSR_RCAS_DPP", "1")[:1] == "0" else "rcas_dpp_kernel"
+        return ["easu_fast_kernel", rcas, "outside_staged_kernel"] if rgba8 else ["fused_kernel", "easu_outside_kernel"]
     return ["easu_fast_kernel"]
 
 
