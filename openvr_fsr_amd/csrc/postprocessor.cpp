@@ -383,6 +383,15 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
                 i = j + 1;
             }
             nSpans_[eye] = (uint32_t)(spans.size() / 2 - spanOff_[eye]);
+            // block b of a launch runs on XCD b % 8 (private L2): give every XCD a contiguous raster run of segments, so that
+            // the 128-byte lines two neighbouring segments share, and the rows two bands share, are fetched once
+            const uint32_t n = nSpans_[eye], full = n & ~7u;
+            std::vector<uint32_t> r(2 * (size_t)n);
+            for (uint32_t b = 0; b < n; ++b) {
+                const uint32_t src = b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b;
+                r[2 * (size_t)b] = spans[2 * (spanOff_[eye] + src)]; r[2 * (size_t)b + 1] = spans[2 * (spanOff_[eye] + src) + 1];
+            }
+            std::copy(r.begin(), r.end(), spans.begin() + 2 * spanOff_[eye]);
         }
     }
     // block b of a launch goes to XCD b % 8: hand every XCD a contiguous run of the (row-major) list
