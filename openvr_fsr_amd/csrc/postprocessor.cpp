@@ -332,6 +332,14 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
     return OVRFSR_OK;
 }
 
+// Block b of a launch runs on XCD b % 8, each XCD with a private L2: entry b of a work list of n row-major items is item
+// xcd_source(b, n), which hands every XCD a contiguous raster run of the list (the n % 8 trailing entries keep their place).
+static inline uint32_t xcd_source(uint32_t b, uint32_t n)
+{
+    const uint32_t full = n & ~7u;
+    return b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b;
+}
+
 // The radius mask is static per eye, so the tiles are sorted once on the host: tiles with at least one 16x16 group
 // inside the radius (EASU kernel, LDS-staged) and tiles entirely outside (bilinear only, LDS-free kernel).
 int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t groupW, uint32_t groupH)
@@ -383,22 +391,21 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
                 i = j + 1;
             }
             nSpans_[eye] = (uint32_t)(spans.size() / 2 - spanOff_[eye]);
-            // block b of a launch runs on XCD b % 8 (private L2): give every XCD a contiguous raster run of segments, so that
-            // the 128-byte lines two neighbouring segments share, and the rows two bands share, are fetched once
-            const uint32_t n = nSpans_[eye], full = n & ~7u;
+            // every XCD a contiguous raster run of segments (xcd_source), so that the 128-byte lines two neighbouring
+            // segments share, and the rows two bands share, are fetched once
+            const uint32_t n = nSpans_[eye];
             std::vector<uint32_t> r(2 * (size_t)n);
             for (uint32_t b = 0; b < n; ++b) {
-                const uint32_t src = b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b;
-                r[2 * (size_t)b] = spans[2 * (spanOff_[eye] + src)]; r[2 * (size_t)b + 1] = spans[2 * (spanOff_[eye] + src) + 1];
+                const size_t src = spanOff_[eye] + xcd_source(b, n);
+                r[2 * (size_t)b] = spans[2 * src]; r[2 * (size_t)b + 1] = spans[2 * src + 1];
             }
             std::copy(r.begin(), r.end(), spans.begin() + 2 * spanOff_[eye]);
         }
     }
-    // block b of a launch goes to XCD b % 8: hand every XCD a contiguous run of the (row-major) list
     auto xcd_order = [](std::vector<uint32_t> &v) {
-        const uint32_t n = (uint32_t)v.size(), full = n & ~7u;
+        const uint32_t n = (uint32_t)v.size();
         std::vector<uint32_t> r(n);
-        for (uint32_t b = 0; b < n; ++b) r[b] = v[b < full ? (b & 7u) * (full >> 3) + (b >> 3) : b];
+        for (uint32_t b = 0; b < n; ++b) r[b] = v[xcd_source(b, n)];
         v.swap(r);
     };
     for (int eye = 0; eye < 2; ++eye) {
