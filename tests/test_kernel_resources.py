@@ -134,3 +134,18 @@ def test_memory_bound_kernels_keep_eight_waves(kernels):
 def test_workgroup_sizes(kernels):
     for k, v in _pick(kernels, r"ovrfsr_(fast|strict)").items():
         assert v["max_flat_workgroup_size"] in (192, 256, 512, 1024), (k, v["max_flat_workgroup_size"])
+
+
+def test_isa_waits_tool_flags_a_wait_between_loads(tmp_path):
+    """tools/isa_waits.py on a synthetic listing: a vmcnt wait between two loads of a block is reported, one after them is not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_waits", os.path.join(ROOT, "tools", "isa_waits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lst = tmp_path / "k.s"
+    lst.write_text("_Z4badkPf:\n\tglobal_load_dwordx4 v[0:3], v8, s[0:1]\n\tglobal_load_dwordx4 v[4:7], v9, s[0:1]\n"
+                   "\ts_waitcnt vmcnt(1)\n\tv_add_f32 v0, v0, v1\n\tglobal_load_dwordx4 v[10:13], v9, s[0:1]\n\ts_endpgm\n"
+                   "_Z5goodkPf:\n\tglobal_load_dword v0, v8, s[0:1]\n\tglobal_load_dword v1, v9, s[0:1]\n"
+                   ".LBB1_2:\n\ts_waitcnt vmcnt(0)\n\tv_add_f32 v0, v0, v1\n\ts_endpgm\n")
+    hits = mod.scan(str(lst))
+    assert [(k, n, before, total) for k, _, n, before, total in hits] == [("_Z4badkPf", "1", 2, 3)]
