@@ -51,8 +51,17 @@ WORKLOADS = {
     "C3r": (1683, 1869, 2244, 2492, torch.uint8, 0.5, 1),    # C3 (NIS) with the shipped radius 0.5
     "C2s": (2244, 2492, 2244, 2492, torch.uint8, 2.0, 0),    # renderScale 1: RCAS only (PostProcessor.cpp:586-594)
     "C3s": (2244, 2492, 2244, 2492, torch.uint8, 2.0, 1),    # renderScale 1 with useNis: NVSharpen only
+    # one SHARED side-by-side texture per frame holding both eyes (what games that submit a single texture with half-width
+    # bounds do: PostProcessor.cpp:146,155-158,298-301), through ovrfsr_apply_batch_shared: a "pair" is ONE 3366x1869 image
+    "C2sbs": (3366, 1869, 4488, 2492, torch.uint8, 2.0, 0),
+    "C2sbsr": (3366, 1869, 4488, 2492, torch.uint8, 0.5, 0),  # the same with the shipped radius 0.5: two mask centres per image
 }
+SHARED = {"C2sbs", "C2sbsr"}   # workloads whose images hold both eyes (images per pair = 1 instead of 2)
 SHARPNESS = 0.9
+
+
+def images_per_pair(workload):
+    return 1 if workload in SHARED else 2
 
 
 # ------------------------------------------------------------------------------------------------
@@ -122,7 +131,8 @@ class GpuShard:
         self.dev = torch.device("cuda", device_index)
         inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
         prec = {"fp32": A.PRECISION_FP32, "strict": A.PRECISION_FP32_STRICT}[args.precision]
-        self.n_img = 2 * args.pairs
+        self.shared = args.workload in SHARED
+        self.n_img = images_per_pair(args.workload) * args.pairs
         with torch.cuda.device(self.dev):
             gen = synth_batch if args.content == "structured" else random_batch
             self.texs = gen(self.n_img, inW, inH, dtype, self.dev, shard_seed(args.pairs, shard_index))
@@ -136,7 +146,12 @@ class GpuShard:
         torch.cuda.set_device(self.dev)     # per host thread
 
     def step(self):
-        self.pp.apply_batch(self.texs, self.outs, first_eye=self.A.EYE_LEFT, alternate_eyes=True)
+        self.pp.apply_batch(self.texs, self.outs, first_eye=self.A.EYE_LEFT, alternate_eyes=True, shared=self.shared)
+
+    def fetch(self, indices):
+        """(input, output) host copies of the given images of the batch the timed call just processed."""
+        self.sync()
+        return [(self.texs[i].cpu().numpy(), self.outs[i].cpu().numpy()) for i in indices]
 
     def sync(self):
         torch.cuda.synchronize(self.dev)
@@ -238,6 +253,108 @@ def max_over_ranks(dt, world, device=None):
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ------------------------------------------------------------------------------------------------
+# self-check of the timed call: the oracle on the very images the timed launch read and wrote
+# ------------------------------------------------------------------------------------------------
+def oracle_expected(workload, img, image_index, nthreads=0):
+    """What the reference's pipeline produces for image `image_index` of a shard (eye = index & 1; a shared side-by-side
+    texture holds both eyes), evaluated by the CPU oracle on the host copy of the GPU's own input.  Same dtype as the
+    GPU output of that workload.  Test infrastructure: only called by the parity_check / cpu_baseline legs."""
+    from oracle import oracle as O
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[workload]
+    eye = 0 if workload in SHARED else image_index & 1
+    one_eye = workload not in SHARED
+    centre, rad = O.mask_constants(outW, outH, radius, (0.5, 0.5, 0.5, 0.5), one_eye, eye)
+    same_size = (inW, inH) == (outW, outH)
+    if use_nis:
+        import openvr_fsr_amd as A
+        f = O.unorm8_to_float(img)
+        if same_size:
+            ok, cfg = A.nis_sharpen_config(SHARPNESS, inW, inH)
+            return O.float_to_unorm8(O.nis_sharpen(f, O.nis_block(cfg, centre, rad, 0), nthreads=nthreads))
+        cs, cu = A.nis_coefs()
+        ok, cfg = A.nis_scaler_config(SHARPNESS, inW, inH, outW, outH)
+        return O.float_to_unorm8(O.nis_upscale(f, outW, outH, O.nis_block(cfg, centre, rad, 0), cs, cu, nthreads=nthreads))
+    if dtype == torch.uint8:
+        if same_size:
+            return O.float_to_unorm8(O.rcas(O.unorm8_to_float(img), O.rcas_con(SHARPNESS), centre, rad, nthreads=nthreads))
+        return O.fsr_pipeline_u8(img, outW, outH, sharpness=SHARPNESS, radius=radius, eye=eye, one_eye_per_texture=one_eye, nthreads=nthreads)
+    # RGBA16F pipeline (C5): EASU in fp32 -> half intermediate -> RCAS in fp32 -> half store
+    e = O.easu(img.astype(np.float32), outW, outH, O.easu_con(inW, inH, outW, outH), centre, rad, nthreads=nthreads)
+    e16 = e.astype(np.float16).astype(np.float32)
+    return O.rcas(e16, O.rcas_con(SHARPNESS), centre, rad, nthreads=nthreads).astype(np.float16)
+
+
+def compare_images(got, want):
+    """Difference record of one image: byte outputs in LSB, half/float outputs in max-abs (unit domain)."""
+    r = {"n_total": int(want.size)}
+    if want.dtype == np.uint8:
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        r.update(max_lsb=int(d.max()), n_diff=int((d != 0).sum()), n_gt1=int((d > 1).sum()))
+    else:
+        g, w = got.astype(np.float32), want.astype(np.float32)
+        d = np.abs(g - w)
+        r.update(max_abs=float(np.max(d)), n_diff=int((got != want).sum()), n_gt_1e3=int((d > 1e-3).sum()),
+                 n_nan=int(np.isnan(g).sum() + np.isnan(w).sum()))
+    return r
+
+
+def check_indices(n_img):
+    """Images {0, 1, n-2, n-1} of the batch: the first and the last stereo pair (blockIdx.z = 0 and the largest)."""
+    return sorted({i for i in (0, 1, n_img - 2, n_img - 1) if 0 <= i < n_img})
+
+
+def parity_and_cpu(args, fetched, indices, want_cpu, budget_s=8.0, max_pairs=8):
+    """The oracle on the images the TIMED launch processed (host copies of shard 0's inputs, downloaded after the timed
+    loop) against the outputs that launch wrote: `parity_check`.  The same oracle calls are the `cpu_baseline` sample --
+    both legs process identical data -- continued on the first pair until ~budget_s of wall time have passed."""
+    from oracle import oracle as O
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
+    cores = min(usable_cores(), O.lib().ovo_max_threads())
+    ipp = images_per_pair(args.workload)
+    recs, imgs_done, dt = [], 0, 0.0   # dt: wall time inside oracle calls only (the comparisons are not CPU-baseline work)
+
+    def timed_oracle(src, i, threads):
+        nonlocal dt, imgs_done
+        t = time.perf_counter()
+        want = oracle_expected(args.workload, src, i, threads)
+        dt += time.perf_counter() - t
+        imgs_done += 1
+        return want
+
+    for (src, got), i in zip(fetched, indices):
+        r = compare_images(got, timed_oracle(src, i, cores))
+        r["image"] = i
+        recs.append(r)
+    if want_cpu:
+        while imgs_done < ipp * max_pairs and dt < budget_s:
+            for k in range(ipp):
+                timed_oracle(fetched[k][0], indices[k], cores)
+    strict = args.precision == "strict"
+    par = {"images": len(recs), "image_indices": indices, "n_total": sum(r["n_total"] for r in recs), "n_diff": sum(r["n_diff"] for r in recs),
+           "call": "the timed ovrfsr_apply_batch%s of shard 0 (%d images per launch); inputs and outputs downloaded after the timed loop, "
+                   "oracle/liboracle.so run on those inputs" % ("_shared" if args.workload in SHARED else "", images_per_pair(args.workload) * args.pairs)}
+    if "max_lsb" in recs[0]:
+        par.update(max_lsb=max(r["max_lsb"] for r in recs), n_gt1=sum(r["n_gt1"] for r in recs))
+        par["tolerance"] = "bit-exact (strict build)" if strict else "<= 1 LSB on UNORM8 outputs"
+        par["ok"] = (par["n_diff"] == 0) if strict else (par["max_lsb"] <= 1)
+    else:
+        par.update(max_lsb=None, max_abs=max(r["max_abs"] for r in recs), n_gt_1e3=sum(r["n_gt_1e3"] for r in recs), n_nan=sum(r["n_nan"] for r in recs))
+        par["tolerance"] = "bit-exact (strict build)" if strict else "max-abs <= 1e-3 on half outputs, no value above it"
+        par["ok"] = (par["n_diff"] == 0) if strict else (par["n_gt_1e3"] == 0 and par["n_nan"] == 0)
+    cpu = None
+    if want_cpu:
+        t1 = time.perf_counter()   # and one image on a single thread (SURVEY.md 8d: report single-thread too)
+        oracle_expected(args.workload, fetched[0][0], indices[0], 1)
+        single = (1.0 / ipp) / (time.perf_counter() - t1)
+        pairs = imgs_done / float(ipp)
+        cpu = {"value": round(pairs / dt, 4), "unit": "eye-pairs/s", "cores": cores, "kind": "port", "single_thread_value": round(single, 4),
+               "sample": "%.1f stereo pair(s) of workload %s (%dx%d->%dx%d), the images the timed GPU launch processed (downloaded), oracle/liboracle.so with "
+                         "%d OpenMP threads (usable cores of this container), %.2f s wall = %.1f core-seconds"
+                         % (pairs, args.workload, inW, inH, outW, outH, cores, dt, dt * cores)}
+    return par, cpu
 
 
 # ------------------------------------------------------------------------------------------------
@@ -384,16 +501,22 @@ def roofline(args, shard):
     ms_step = time_events(shard.step, iters, stream)
     kernels = dominant_kernels(args.workload)
     single_pass = len(kernels) > 1 or use_nis or (inW, inH) == (outW, outH)
+    sclk = SclkSampler(shard.device_index)   # shader clock while the dominant kernel runs (valu.issue_frac needs cycles, not nominal GHz)
     if single_pass:
         # masked / NIS / sharpen-only: the step IS the kernel (plus its concurrent companions when masked)
-        ms_dom, dom_bytes, out_px = ms_step, algo_bytes_eye * n_img, outW * outH * n_img
+        with sclk:
+            ms_dom = time_events(shard.step, max(iters, 10), stream)
+        dom_bytes, out_px = algo_bytes_eye * n_img, outW * outH * n_img
     else:
         # dominant kernel of the two-pass pipeline: EASU -- launched alone over the same batch
         kw = dict(shard.cfg_kw, stage_mask=1)
         pe = A.PostProcessor(cfg=A.Config.default(**kw), device=shard.device_index)
-        ms_dom = time_events(lambda: pe.apply_batch(shard.texs, shard.outs, first_eye=A.EYE_LEFT, alternate_eyes=True), iters, stream)
+        with sclk:
+            ms_dom = time_events(lambda: pe.apply_batch(shard.texs, shard.outs, first_eye=A.EYE_LEFT, alternate_eyes=True, shared=shard.shared),
+                                 max(iters, 10), stream)
         pe.close()
         dom_bytes, out_px = bpp * (inW * inH + outW * outH) * n_img, outW * outH * n_img
+    sclk_mhz = sclk.mean_mhz()
     ach = dom_bytes / (ms_dom * 1e-3) / 1e9
     pipe = algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9
     copy_gbps = copy_ceiling_gbps(dev)
@@ -402,15 +525,17 @@ def roofline(args, shard):
             "launch_ms": round(ms_dom, 4), "algorithmic_bytes_per_launch": dom_bytes,
             "copy_ceiling": round(copy_gbps, 1), "frac_of_copy": round(ach / copy_gbps, 4),
             "pipeline_ms_per_step_events": round(ms_step, 4), "pipeline_achieved_GBps": round(pipe, 1),
-            "pipeline_frac": round(pipe / HBM_PEAK_GBPS, 4), "binding_roof": "valu_issue", "valu": None}
+            "pipeline_frac": round(pipe / HBM_PEAK_GBPS, 4), "binding_roof": "valu_issue", "valu": None,
+            "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_source": sclk.source, "sclk_samples": len(sclk.samples)}
     pmc = pmc_counters(args) if args.pmc == "auto" else None
     if pmc:
-        scale = n_img / (2.0 * PMC_CHILD_PAIRS)   # counters were read on launches of 2*PMC_CHILD_PAIRS images
+        child_img = images_per_pair(args.workload) * PMC_CHILD_PAIRS
+        scale = n_img / float(child_img)   # counters were read on launches of child_img images
         hit = {k: v for k, v in pmc.items() if k in kernels}
         if hit and all("FETCH_SIZE" in v and "WRITE_SIZE" in v for v in hit.values()):
             # WRITE_SIZE + 2 x FETCH_SIZE, KiB per dispatch (gfx950: FETCH_SIZE reports half the bytes of a coalesced read)
             roof["traffic"] = int(sum(v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"] for v in hit.values()) * 1024.0 * scale)
-            roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (launches of %d images, scaled to %d)" % (2 * PMC_CHILD_PAIRS, n_img)
+            roof["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (launches of %d images, scaled to %d)" % (child_img, n_img)
             roof["traffic_per_kernel"] = {k: int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024.0 * scale) for k, v in hit.items()}
         if hit and all("SQ_INSTS_VALU" in v for v in hit.values()):
             instr = sum(v["SQ_INSTS_VALU"] for v in hit.values()) * scale          # wave-instructions per launch (step)
@@ -436,27 +561,160 @@ def roofline(args, shard):
     return roof
 
 
-def cpu_baseline(inW, inH, outW, outH, sharpness):
-    """The oracle (C restatement, OpenMP) on stereo pairs of the same workload, one thread per usable core, for a
-    bounded sample: pairs are processed until ~8 s of wall time have passed (at least one, at most eight)."""
-    from oracle import oracle as O
-    from tests import synth
-    cores = min(usable_cores(), O.lib().ovo_max_threads())
-    imgs = [synth.structured_u8(inW, inH, synth.seed_for(0, e)) for e in range(2)]
-    O.fsr_pipeline_u8(imgs[0][:64, :64].copy(), 85, 85, sharpness=sharpness)  # warm the library
-    pairs, t0 = 0, time.perf_counter()
-    while pairs < 8 and (pairs == 0 or time.perf_counter() - t0 < 8.0):
-        for im in imgs:
-            O.fsr_pipeline_u8(im, outW, outH, sharpness=sharpness, nthreads=cores)
-        pairs += 1
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()   # and one eye on a single thread (SURVEY.md 8d: report single-thread too)
-    O.fsr_pipeline_u8(imgs[0], outW, outH, sharpness=sharpness, nthreads=1)
-    single = 0.5 / (time.perf_counter() - t1)
-    return {"value": round(pairs / dt, 4), "unit": "eye-pairs/s", "cores": cores, "kind": "port", "single_thread_value": round(single, 4),
-            "sample": "%d stereo pair(s) %dx%d->%dx%d RGBA8, EASU+RCAS (UNORM8 intermediate), oracle/liboracle.so with %d OpenMP "
-                      "threads (usable cores of this container), %.2f s wall = %.1f core-seconds"
-                      % (pairs, inW, inH, outW, outH, cores, dt, dt * cores)}
+class SclkSampler:
+    """Mean shader clock (MHz) of one device while a loop runs: a host thread polls amdsmi (or the driver's sysfs node)
+    every few milliseconds.  None when neither is readable in this container."""
+
+    def __init__(self, device_index, period_s=0.004):
+        self.idx, self.period, self.samples, self._stop, self._thr = device_index, period_s, [], False, None
+        self._read = self._probe()
+
+    def _probe(self):
+        try:
+            import amdsmi
+            try:
+                amdsmi.amdsmi_init()
+            except Exception:  # noqa: BLE001 -- already initialised
+                pass
+            h = amdsmi.amdsmi_get_processor_handles()[self.idx]
+
+            def read():
+                info = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                v = info.get("clk", info.get("cur_clk"))
+                return float(v) if isinstance(v, (int, float)) and v > 0 else None
+            if read() is not None:
+                self.source = "amdsmi_get_clock_info(GFX)"
+                return read
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            import glob
+            nodes = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+            node = nodes[min(self.idx, len(nodes) - 1)]
+
+            def read_sysfs():
+                for line in open(node).read().splitlines():
+                    if line.rstrip().endswith("*"):
+                        return float(re.search(r"(\d+)\s*[Mm][Hh]z", line).group(1))
+                return None
+            if read_sysfs() is not None:
+                self.source = node
+                return read_sysfs
+        except Exception:  # noqa: BLE001
+            pass
+        self.source = None
+        return None
+
+    def __enter__(self):
+        if self._read:
+            def loop():
+                while not self._stop:
+                    try:
+                        v = self._read()
+                        if v:
+                            self.samples.append(v)
+                    except Exception:  # noqa: BLE001
+                        pass
+                    time.sleep(self.period)
+            self._thr = threading.Thread(target=loop, daemon=True)
+            self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thr:
+            self._thr.join()
+
+    def mean_mhz(self):
+        return sum(self.samples) / len(self.samples) if self.samples else None
+
+
+def content_random_leg(args, shard, steps):
+    """The same workload and launch on the second distribution of SURVEY.md 8d -- uniform-random texels: no smooth regions,
+    every NVScaler wave on its 4-direction path, dense near-tie lists -- un-timed for the headline, reported beside it.
+    Image 0 of that batch is checked against the oracle as well."""
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
+    keep = shard.texs
+    stream = torch.cuda.current_stream(shard.dev)
+    try:
+        shard.texs = random_batch(shard.n_img, inW, inH, dtype, shard.dev, shard_seed(args.pairs, shard.shard_index) ^ 0x00A5A500)
+        ms = time_events(shard.step, max(5, steps), stream)
+        (src, got), = shard.fetch([0])
+        r = compare_images(got, oracle_expected(args.workload, src, 0))
+        ok = (r["n_diff"] == 0) if args.precision == "strict" else (r["max_lsb"] <= 1 if "max_lsb" in r else r["n_gt_1e3"] == 0 and r["n_nan"] == 0)
+        return {"content": "uniform random texels", "value": round(args.pairs / (ms * 1e-3), 2), "unit": "eye-pairs/s", "ms_per_step": round(ms, 4),
+                "parity_image0": dict(r, ok=bool(ok))}
+    finally:
+        shard.texs = keep
+
+
+def frame_leg(args, shard, frames=520):
+    """The reference's OWN performance figure: GPU time per frame for ONE submitted stereo pair, as its debug mode logs it
+    ("Average GPU processing time for upscale", PostProcessor.cpp:605-626: timestamps around every Apply, ring of 6, mean of
+    500 readings, x2 when each eye has its own texture) -- read through ovrfsr_average_gpu_time_ms from `frames` stereo
+    submissions (L, R, L, R ... one ovrfsr_apply per eye, as the Submit detours call it).  Beside it: the same two applies
+    captured in a HIP graph and replayed (what a host that pre-records its frame would see), and issued directly."""
+    A = shard.A
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
+    if args.workload in SHARED or shard.n_img < 2:
+        return None
+    L, R, oL, oR = shard.texs[0], shard.texs[1], shard.outs[0], shard.outs[1]
+    dev = shard.dev
+
+    def one(radius_v):
+        rec = {"radius": radius_v}
+        pp = A.PostProcessor(device=shard.device_index, **dict(shard.cfg_kw, radius=radius_v, debug_mode=1))
+        try:
+            for _ in range(frames):
+                pp.apply(A.EYE_LEFT, L, out=oL)
+                pp.apply(A.EYE_RIGHT, R, out=oR)
+            torch.cuda.synchronize(dev)
+            ms, reports = pp.average_gpu_time_ms()
+            rec.update(gpu_ms_per_frame=round(ms, 5) if reports else None, reports=reports)
+        finally:
+            pp.close()
+        pp = A.PostProcessor(device=shard.device_index, **dict(shard.cfg_kw, radius=radius_v))
+        try:
+            def frame():
+                pp.apply(A.EYE_LEFT, L, out=oL)
+                pp.apply(A.EYE_RIGHT, R, out=oR)
+
+            def wall_ms(fn, it=200):
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(it):
+                    fn()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t0) / it * 1e3
+            frame(); frame()
+            rec["direct_ms_per_frame"] = round(wall_ms(frame), 5)
+            try:
+                g = torch.cuda.CUDAGraph()
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(g, stream=side):
+                        frame()
+                torch.cuda.synchronize(dev)
+                rec["graph_ms_per_frame"] = round(wall_ms(g.replay), 5)
+            except Exception as e:  # noqa: BLE001 -- graph capture is optional evidence, never fatal for the bench line
+                rec["graph_ms_per_frame"] = None
+                rec["graph_error"] = str(e)[:120]
+        finally:
+            pp.close()
+        return rec
+
+    out = {"pairs_per_call": 1, "applies_per_frame": 2, "frames": frames,
+           "method": "gpu_ms_per_frame = ovrfsr_average_gpu_time_ms (debug_mode=1: the reference's ring of 6 timestamp pairs, mean of 500, x2 per-eye "
+                     "textures, PostProcessor.cpp:605-626); graph/direct = wall time per frame of the two applies replayed from a HIP graph / issued from Python"}
+    first = one(radius)
+    out.update({k: v for k, v in first.items() if k != "radius"})
+    out["radius"] = radius
+    if radius != 0.5 and not (inW, inH) == (outW, outH):
+        out["shipped_radius_0.5"] = one(0.5)   # openvr_mod.cfg's default: what a user of the reference runs
+    return out
 
 
 def parse_args(argv=None):
@@ -475,6 +733,8 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: map shard i to device i %% device_count (exercise the N>1 launchers on a box with fewer GPUs)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed call's outputs (parity_check)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the un-timed extra legs (content_random, frame)")
     ap.add_argument("--content", default="structured", choices=["structured", "random"],
                     help="synthetic eye content: structured (gradients+edges+noise, default) or uniform random")
     return ap.parse_args(argv)
@@ -490,15 +750,40 @@ def plan(args, env):
     return 1, 0, list(range(max(1, args.gpus))), 0
 
 
-def main():
-    args = parse_args()
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+def shard_factory():
+    """GpuShard, or -- for the launcher tests only -- the factory named by OVRFSR_BENCH_SHARD_FACTORY ("module:callable",
+    called as f(device_index, shard_index, args)): lets tests/test_bench_launcher.py run EXACTLY the commands the round driver
+    runs (`bench.py --gpus N`, and the same under torch.distributed.run) on a box without GPUs.  A mocked run carries
+    "mock_shards": true in its line and no roofline / parity / cpu legs."""
+    spec = os.environ.get("OVRFSR_BENCH_SHARD_FACTORY")
+    if not spec:
+        return None
+    import importlib
+    mod, fn = spec.split(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
+def gather_over_ranks(values, world):
+    """Per-device timings of every rank, in rank order (host-side gather of a few floats over gloo)."""
+    if world == 1:
+        return list(values)
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, list(values))
+    return [v for part in out for v in part]
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    mock = shard_factory()
+    assert mock or torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
     if args.pmc_child:
         return pmc_child(args)
     world, rank, devices, first_shard = plan(args, os.environ)
+    n_visible = max(devices) + 1 if mock else torch.cuda.device_count()
     if args.oversubscribe:
-        devices = [d % torch.cuda.device_count() for d in devices]
-    assert max(devices) < torch.cuda.device_count(), "--gpus %d but only %d device(s) visible" % (args.gpus, torch.cuda.device_count())
+        devices = [d % n_visible for d in devices]
+    assert max(devices) < n_visible, "--gpus %d but only %d device(s) visible" % (args.gpus, n_visible)
     cross = None
     if world > 1:
         import torch.distributed as dist
@@ -516,46 +801,64 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
         cross = dist.barrier
-    torch.cuda.set_device(devices[0])
-    shards = build_shards(len(devices), first_shard, lambda i, s: GpuShard(devices[i], s, args))
+    if not mock:
+        torch.cuda.set_device(devices[0])
+    make = mock or GpuShard
+    shards = build_shards(len(devices), first_shard, lambda i, s: make(devices[i], s, args))
     n_gpus = world * len(devices)
 
-    dt_local, dev_ms = run_local(shards, args.steps, args.warmup, CLOCK_RAMP_S, cross)
+    dt_local, dev_ms = run_local(shards, args.steps, args.warmup, 0.0 if mock else CLOCK_RAMP_S, cross)
     dt = max_over_ranks(dt_local, world)
+    dev_ms = gather_over_ranks(dev_ms, world)   # one entry per GPU of the job, whatever the launcher
 
     inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
     value = args.pairs * n_gpus * args.steps / dt
-    roof = cpu = None
+    roof = cpu = par = None
+    bad = False
     if rank == 0:
         shards[0].bind()
-        roof = roofline(args, shards[0])
-        if n_gpus == 1 and not args.no_cpu and not use_nis and dtype == torch.uint8:  # CPU baseline: N=1 only
-            cpu = cpu_baseline(inW, inH, outW, outH, SHARPNESS)
+        extras = {"mock_shards": True} if mock else {}
+        # the outputs of the TIMED launches, before anything else writes the output batch
+        indices = check_indices(images_per_pair(args.workload) * args.pairs)
+        fetched = None if (args.no_verify or mock) else shards[0].fetch(indices)
+        roof = None if mock else roofline(args, shards[0])
+        if n_gpus == 1 and not args.no_extras and not mock:
+            if args.content == "structured":
+                extras["content_random"] = content_random_leg(args, shards[0], args.steps // 2)
+            extras["frame"] = frame_leg(args, shards[0])
+        if fetched is not None:
+            par, cpu = parity_and_cpu(args, fetched, indices, want_cpu=(n_gpus == 1 and not args.no_cpu))   # CPU baseline: N=1 only
+            bad = not par["ok"]
+        shape = ("%dx%d->%dx%d" % (inW, inH, outW, outH)) + (" side-by-side textures holding both eyes" if args.workload in SHARED else "")
         line = {
             "metric": "stereo eye-pairs/sec at 1683x1869->2244x2492 (EASU+RCAS)" if args.workload == "C2"
                       else "stereo eye-pairs/sec (%s)" % args.workload,
             "value": round(value, 2), "unit": "eye-pairs/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (%s)" % args.content,
-            "config": {"workload": "%s: stereo pairs %dx%d->%dx%d %s, %s, sharpness 0.9, radius %.1f"
-                                   % (args.workload, inW, inH, outW, outH, "RGBA8" if dtype == torch.uint8 else "RGBA16F",
+            "config": {"workload": "%s: stereo pairs %s %s, %s, sharpness 0.9, radius %.1f"
+                                   % (args.workload, shape, "RGBA8" if dtype == torch.uint8 else "RGBA16F",
                                       ("NIS NVSharpen" if (inW, inH) == (outW, outH) else "NIS NVScaler") if use_nis else
-                                      ("RCAS" if (inW, inH) == (outW, outH) else "EASU+RCAS (UNORM8 intermediate)"), radius),
+                                      ("RCAS" if (inW, inH) == (outW, outH) else "EASU+RCAS (UNORM8 intermediate)" if dtype == torch.uint8
+                                       else "EASU+RCAS (half intermediate)"), radius),
                        "pairs_per_gpu_per_step": args.pairs, "precision": args.precision, "clock_ramp_s": CLOCK_RAMP_S,
                        "launcher": "torchrun, one rank per GPU, gloo timing barrier" if world > 1
                                    else "one process, %d device(s), one host thread + stream per device" % len(devices),
                        "per_device_ms_per_step": [round(m / args.steps, 4) for m in dev_ms],
-                       **({"oversubscribed": "TEST RUN: %d shards on %d device(s), not a scaling measurement" % (n_gpus, torch.cuda.device_count())}
+                       **({"oversubscribed": "TEST RUN: %d shards on %d device(s), not a scaling measurement" % (n_gpus, n_visible)}
                           if args.oversubscribe else {}),
                        "parallelism": "batch sharded over %d GPU(s), no collective" % n_gpus},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "parity_check": par, **extras,
         }
         print(json.dumps(line))
+        sys.stdout.flush()
     for s in shards:
         s.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if bad:   # the line above says so too ("parity_check": {"ok": false}); a number for wrong pixels is not a result
+        sys.exit("bench.py: the timed call's outputs differ from the oracle beyond the stated tolerance")
 
 
 if __name__ == "__main__":

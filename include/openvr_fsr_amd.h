@@ -66,10 +66,14 @@ typedef enum ovrfsr_format {
 /* Arithmetic the kernels run in.  The reference only ever compiles the fp32 bodies
  * (`//#define A_HALF`, src/fsr/fsr_easu.hlsl:3).
  *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp): the product build.  Its quantised EASU stores
- *                (the UNORM8 / half intermediate, an EASU-only UNORM8 output) are nevertheless the STRICT build's, bit for bit:
- *                pixels whose result lies within 2^-9 byte (2^-17 for half) of a rounding boundary are re-resolved in the
- *                reference's operator order (near-tie guard); float outputs differ by <= 3e-6, UNORM8 pipeline
- *                outputs by <= 1 LSB
+ *                (the UNORM8 / half intermediate, an EASU-only UNORM8 output) are nevertheless the STRICT build's -- EMPIRICALLY bit for
+ *                bit: pixels whose result lies within 2^-9 byte (for half stores: 2^-6 of a half spacing, values in
+ *                [xmin, 2) with xmin = 0.25 / 0.5 derived from the sharpness) of a rounding boundary are re-resolved in the
+ *                reference's operator order (near-tie guard).  The band is 3x the largest re-association error
+ *                MEASURED (6.5e-4 byte over 1e8 values incl. adversarial content, tools/debug/easu_err.py is the audit:
+ *                it re-resolves every pixel with the strict build and reports any value outside the band); it is not a
+ *                derived bound, and HDR half inputs whose taps span many binades are outside what was measured.  Float
+ *                outputs differ by <= 3e-6, UNORM8 pipeline outputs by <= 1 LSB
  *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
  *                to the CPU oracle; a validation build, not a fast one
  * There is no packed-half arithmetic mode (value 1 was reserved for one in ABI 1 and is rejected with
@@ -103,7 +107,13 @@ typedef struct ovrfsr_config {
     uint32_t struct_size;    /* = sizeof(ovrfsr_config); ABI guard                               */
     int32_t fsr_enabled;     /* Config::fsrEnabled: 0 -> apply() is a pass-through (output = input
                                 handle untouched, PostProcessor.cpp:135)                         */
-    int32_t use_nis;         /* Config::useNis                                                   */
+    int32_t use_nis;         /* Config::useNis.  DEPARTURE FROM THE REFERENCE, NVScaler only: the reference ignores
+                                NVScalerUpdateConfig's `false` for a scale outside [0.5, 1] (in/out; i.e. upscales
+                                beyond 2x, or any render_scale > 1) and dispatches with a half-initialised NISConfig
+                                block (PostProcessor.cpp:308, NIS_Config.h:144-160: the result is undefined).  Here
+                                such a configuration fails the (re)build: ovrfsr_apply* returns
+                                OVRFSR_ERR_UNSUPPORTED, the ctx disables itself like any failed PrepareResources
+                                (PostProcessor.cpp:148-151) and the caller's texture goes through untouched       */
     int32_t debug_mode;      /* Config::debugMode: tints pixels outside the radius               */
     float render_scale;      /* Config::renderScale; <1: out = in / scale, >=1: out = in * scale,
                                 both truncated to uint (PostProcessor.cpp:512-518)               */

@@ -1,6 +1,7 @@
 // fsr_kernels.hip -- instantiates the gfx950 FSR1 kernels twice (product build and strict
 // validation build, see fsr_kernels.inc) and exposes typed launchers to the host launch manager.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include "fsr_params.h"
@@ -136,19 +137,33 @@ template <int I, int M, int O>
 static hipError_t fused_go3(bool strict, const FusedArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
     const int pitch = easu_fast_pitch(a.cellsW);
-    // the EASU planes plus the 34x34 intermediate can exceed the 64 KiB default cap on dynamic LDS (160 KiB per CU)
-    auto raise = [](const void *fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsMax); };
+    // the EASU planes plus the 34x34 intermediate can exceed the 64 KiB default cap on dynamic LDS (160 KiB per CU).  The
+    // attribute is per DEVICE (a one-process node driver holds one ctx per device, examples/bench_node.c): latched per
+    // (kernel instantiation, device), one bit per device ordinal.
+    auto raise = [](const void *fn, std::atomic<uint64_t> &done) -> hipError_t {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsMax);
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+        return e;
+    };
     if (strict) {
-        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_strict::fused_kernel<I, M, O, 0>));
-        if (once != hipSuccess) return once;
+        static std::atomic<uint64_t> done{0};
+        const hipError_t e = raise(reinterpret_cast<const void *>(&ovrfsr_strict::fused_kernel<I, M, O, 0>), done);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL((ovrfsr_strict::fused_kernel<I, M, O, 0>), grid, dim3(kThreads), lds, s, a);
     } else if (pitch == 32) {
-        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>));
-        if (once != hipSuccess) return once;
+        static std::atomic<uint64_t> done{0};
+        const hipError_t e = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>), done);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, a);
     } else if (pitch == 40) {
-        static const hipError_t once = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>));
-        if (once != hipSuccess) return once;
+        static std::atomic<uint64_t> done{0};
+        const hipError_t e = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>), done);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, a);
     } else {
         return hipErrorInvalidValue;
@@ -245,7 +260,7 @@ hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuA
     EasuArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || nTiles == 0) return hipErrorInvalidValue;
-    if (a.bilX && a.bilY && outside_staged_ok(a.v, in_fmt)) {
+    if (a.bilX && a.bilY && a.tileRec && outside_staged_ok(a.v, in_fmt)) { // no records: the per-pixel kernel below needs none
         OutsideArgs o;
         o.v = a.v; o.tilesX = a.tilesX; o.tileList = a.tileList; o.tileRec = a.tileRec; o.bilX = a.bilX; o.bilY = a.bilY; o.debug = a.debug;
         o.lds_cols = a.outsideCols; o.lds_rows = a.outsideRows;

@@ -79,7 +79,7 @@ hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a_in, uint
     NisArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || nGroups == 0) return hipErrorInvalidValue;
-    if (a.bilX && a.bilY && outside_staged_ok(a.v, in_fmt)) {
+    if (a.bilX && a.bilY && a.tileRec && outside_staged_ok(a.v, in_fmt)) { // no records: the per-pixel kernel below needs none
         OutsideArgs o;
         o.v = a.v; o.tilesX = a.tilesX; o.tileList = a.tileList; o.tileRec = a.tileRec; o.bilX = a.bilX; o.bilY = a.bilY; o.debug = a.reserved1 != 0.0f ? 1u : 0u;
         o.lds_cols = a.outsideCols; o.lds_rows = a.outsideRows;

@@ -102,6 +102,7 @@ void PostProcessor::Reset()
     nInside_[0] = nInside_[1] = nOutside_[0] = nOutside_[1] = nRing_[0] = nRing_[1] = 0;
     nisCoefDev_ = nullptr;
     bilinDev_ = nullptr;
+    bilinHost_.clear(); // never let taps of a previous configuration reach PrepareTileLists' footprint records
     upscaled_ = sharpened_ = nullptr;
     upscaledBytes_ = sharpenedBytes_ = 0;
     lastSubmittedTexture_ = nullptr;
@@ -886,8 +887,6 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
         rc = CheckImage(out, "out");
         if (rc != OVRFSR_OK) return rc;
         if (out->width != outputWidth_ || out->height != outputHeight_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "out has the wrong size");
-        // an in-place call (plausible in sharpen-only mode, where the sizes agree) would race: RCAS / NVSharpen read neighbour texels
-        if (RangesOverlap(*in, 0, *out, 0, 1)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output images overlap");
         dst = *out;
     } else {
         dst.width = outputWidth_; dst.height = outputHeight_;
@@ -897,6 +896,10 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
         if (rc != OVRFSR_OK) return rc;
         dst.data = sharpened_;
     }
+    // an in-place call would race: RCAS / NVSharpen / EASU read neighbour texels other workgroups overwrite.  Checked against the
+    // RESOLVED destination -- the caller's buffer or the ctx-owned one: chaining the previous ctx-owned result back in as `in`
+    // (sharpen-only mode, where the sizes agree) is the same race
+    if (stages && RangesOverlap(*in, 0, dst, 0, 1)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output images overlap");
 
     // a shared side-by-side texture is processed once, on the first Submit (:155-158)
     if (eyeCount_ == 0 || textureContainsOnlyOneEye_ || in->data != lastSubmittedTexture_) {

@@ -77,3 +77,61 @@ def test_a_failing_shard_does_not_hang_the_others():
         pass
     else:
         raise AssertionError("expected the failure to propagate")
+
+
+# ------------------------------------------------------------------------------------------------
+# the round driver's own commands, end to end, with the GPU shard mocked (tests/mock_shard.py)
+# ------------------------------------------------------------------------------------------------
+import json  # noqa: E402
+import os  # noqa: E402
+import subprocess  # noqa: E402
+import sys  # noqa: E402
+
+import pytest  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, timeout=180):
+    env = dict(os.environ, OVRFSR_BENCH_SHARD_FACTORY="tests.mock_shard:make", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "exactly ONE line on stdout, got %r" % lines   # the driver parses stdout as one JSON object
+    return json.loads(lines[0])
+
+
+def _check_line(d, n, steps, warmup, pairs):
+    from tests import mock_shard
+    assert d["n_gpus"] == n and d["steps"] == steps and d["warmup"] == warmup and d["unit"] == "eye-pairs/s"
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    per_dev = d["config"]["per_device_ms_per_step"]
+    assert len(per_dev) == n                                               # one entry per GPU of the job, whatever the launcher
+    assert per_dev == sorted(per_dev) and per_dev[-1] >= mock_shard.STEP_S * n * 1e3 * 0.9   # shard i sleeps (i+1) x STEP_S
+    # whole-job value = N x pairs x steps / time of the slowest shard
+    assert d["ms_per_step"] >= per_dev[-1] * 0.95
+    assert d["value"] == pytest.approx(n * pairs * steps / (d["ms_per_step"] * 1e-3 * steps), rel=1e-3)
+    assert d["config"]["pairs_per_gpu_per_step"] == pairs and d.get("mock_shards") is True
+
+
+@pytest.mark.timeout(300)
+def test_driver_command_direct_8_gpus():
+    """`python bench.py --gpus 8 --steps K --warmup W`: one process, 8 shards."""
+    d = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    _check_line(d, 8, 5, 2, 64)
+    assert "one process, 8 device(s)" in d["config"]["launcher"]
+
+
+@pytest.mark.timeout(300)
+def test_driver_command_under_torch_distributed_run():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N
+    --steps K --warmup W` -- the driver's N > 1 launch: one rank per GPU, rank 0 prints the one line, every rank's device time
+    arrives through the gloo gather."""
+    n = 4
+    port = 29600 + (os.getpid() % 300)
+    d = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+              "--master-port", str(port), "bench.py", "--gpus", str(n), "--steps", "5", "--warmup", "2"])
+    _check_line(d, n, 5, 2, 64)
+    assert "torchrun" in d["config"]["launcher"]

@@ -483,6 +483,12 @@ def test_in_place_apply_is_rejected(gpu):
         out = torch.empty_like(t)
         pp.apply(0, t, out=out)      # the ctx is still usable
         torch.cuda.synchronize()
+        # the same race through the ctx-owned output: chaining the previous ctx-owned result back in as `in` with out = NULL
+        own = pp.apply(0, t)         # ctx-owned destination
+        torch.cuda.synchronize()
+        with pytest.raises(A.OvrFsrError) as e:
+            pp.apply(0, own)         # would sharpen the ctx-owned image in place
+        assert e.value.status == 1
         pp.close()
 
 

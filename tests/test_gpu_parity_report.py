@@ -4,7 +4,7 @@ Each case runs the HIP path through the C ABI and the CPU oracle on the same see
   max_abs   largest |difference| on float outputs (unit domain)
   max_lsb   largest byte difference on UNORM8 outputs
   n_diff    how many channel values differ at all, of n_total
-into gpurun_out/parity_r03.json (merged back from the GPU box; the copy under profiles/ is the committed record).
+into gpurun_out/parity_r04.json (merged back from the GPU box; the copy under profiles/ is the committed record).
 The asserts are the stated tolerances:
   strict build   bit-exact everywhere (n_diff == 0)
   product build  float outputs max-abs <= 1e-3 (north_star), measured ~3e-6;
@@ -36,7 +36,7 @@ def _write_report():
         return
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "parity_r03.json"), "w") as f:
+    with open(os.path.join(out_dir, "parity_r04.json"), "w") as f:
         json.dump({"note": "HIP path vs CPU oracle at full BASELINE sizes; written by tests/test_gpu_parity_report.py",
                    "records": _RECORDS}, f, indent=1)
 
@@ -93,8 +93,6 @@ def test_c1_easu_only(gpu, content):
 def test_fsr_pipeline(gpu, cfg, iw, ih, ow, oh, radius, content):
     """C2 / C2r (shipped radius 0.5) / C4 (renderScale 1.3 shape): EASU -> UNORM8 -> RCAS -> UNORM8, and the same
     pipeline with float intermediate and output (the form north_star's 1e-3 is meaningful on)."""
-    if cfg != "C2" and content == "random":
-        pytest.skip("random content is covered at C2 (C1, C3 as well)")
     img8 = GEN[content](iw, ih, synth.seed_for(0, 1))
     want8 = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9, radius=radius, eye=1)
     _, wantf = O.fsr_pipeline_u8(img8, ow, oh, sharpness=0.9, radius=radius, eye=1, quantize_intermediate=False, want_float=True)
@@ -121,8 +119,6 @@ def test_fsr_pipeline(gpu, cfg, iw, ih, ow, oh, radius, content):
 @pytest.mark.parametrize("content", ["structured", "random"])
 def test_nis_scaler(gpu, cfg, radius, content):
     """C3 / C3r: NVScaler 1683x1869 -> 2244x2492."""
-    if cfg == "C3r" and content == "random":
-        pytest.skip("random content is covered at C3")
     iw, ih, ow, oh = 1683, 1869, 2244, 2492
     img8 = GEN[content](iw, ih, synth.seed_for(1, 0))
     want = _nis_want(img8, ow, oh, 0.9, radius)
@@ -136,20 +132,72 @@ def test_nis_scaler(gpu, cfg, radius, content):
     assert r["max_lsb"] <= 1, r
 
 
-def test_c5_masked_half(gpu):
-    """C5: radius-masked EASU+RCAS, 2370x2370 -> 3160x3160, RGBA16F in, half intermediate, RGBA16F out."""
+def _c5_case(gen, seed):
     iw, ih, ow, oh = 2370, 2370, 3160, 3160
-    imgh = (synth.structured_u8(iw, ih, 77).astype(np.float32) / 255.0).astype(np.float16)
+    imgh = (gen(iw, ih, seed).astype(np.float32) / 255.0).astype(np.float16)
     centre, rad = O.mask_constants(ow, oh, 0.5)
     e = O.easu(imgh.astype(np.float32), ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
     e16 = e.astype(np.float16).astype(np.float32)
-    want = O.rcas(e16, O.rcas_con(0.9), centre, rad).astype(np.float16)
-    r = _rec("C5", "strict", "structured", "half", run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5), want)
+    return imgh, O.rcas(e16, O.rcas_con(0.9), centre, rad).astype(np.float16)
+
+
+@pytest.mark.parametrize("content,seed", [("structured", 77), ("structured", 78), ("random", 79)])
+def test_c5_masked_half(gpu, content, seed):
+    """C5: radius-masked EASU+RCAS, 2370x2370 -> 3160x3160, RGBA16F in, half intermediate, RGBA16F out (two structured images and
+    a uniform-random one)."""
+    ow, oh = 3160, 3160
+    imgh, want = _c5_case(GEN[content], seed)
+    tag = "%s (seed %d)" % (content, seed)
+    r = _rec("C5", "strict", tag, "half", run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5), want)
     assert r["n_diff"] == 0
-    r = _rec("C5", "product", "structured", "half", run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5), want)
+    r = _rec("C5", "product", tag, "half", run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5), want)
     # the half intermediate's near-ties are re-resolved in the reference's operator order wherever a flipped half-ulp could
     # exceed the tolerance behind RCAS's gain (near_tie_half): north_star's bound holds on every value
     assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C2r", "C5", "C2sbsr"])
+def test_timed_call_full_size(gpu, cfg):
+    """The call bench.py times -- ovrfsr_apply_batch over a batch of full-size images (L,R,L,R..., blockIdx.z > 0, XCD-ordered
+    tile indices, per-eye mask lists) -- product build, EVERY image against the oracle.  (The other records of this file go
+    through single-image ovrfsr_apply.)  C2sbsr: the shared side-by-side form, ovrfsr_apply_batch_shared."""
+    import torch
+    import openvr_fsr_amd as A
+    n = 6
+    shared = cfg == "C2sbsr"
+    iw, ih, ow, oh, radius = {"C2": (1683, 1869, 2244, 2492, 2.0), "C2r": (1683, 1869, 2244, 2492, 0.5),
+                              "C5": (2370, 2370, 3160, 3160, 0.5), "C2sbsr": (3366, 1869, 4488, 2492, 0.5)}[cfg]
+    if shared:
+        n = 3
+    half = cfg == "C5"
+    gens = [synth.structured_u8, synth.structured_u8, synth.random_u8]
+    imgs8 = [gens[i % 3](iw, ih, synth.seed_for(10 + i // 2, i & 1)) for i in range(n)]
+    if half:
+        src = np.stack([(im.astype(np.float32) / 255.0).astype(np.float16) for im in imgs8])
+    else:
+        src = np.stack(imgs8)
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.9, radius=radius, precision=FP32)
+    t = torch.from_numpy(src).cuda()
+    outs = torch.empty((n, oh, ow, 4), dtype=t.dtype, device="cuda")
+    pp.apply_batch(t, outs, first_eye=A.EYE_LEFT, alternate_eyes=True, shared=shared)
+    torch.cuda.synchronize()
+    got = outs.cpu().numpy()
+    pp.close()
+    centre_rad = None
+    for i in range(n):
+        eye = 0 if shared else i & 1
+        if half:
+            centre, rad = O.mask_constants(ow, oh, radius, (0.5,) * 4, True, eye)
+            e = O.easu(src[i].astype(np.float32), ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
+            want = O.rcas(e.astype(np.float16).astype(np.float32), O.rcas_con(0.9), centre, rad).astype(np.float16)
+        else:
+            want = O.fsr_pipeline_u8(imgs8[i], ow, oh, sharpness=0.9, radius=radius, eye=eye, one_eye_per_texture=not shared)
+        r = _rec(cfg + " batched (image %d of %d)" % (i, n), "product", "random" if i % 3 == 2 else "structured",
+                 "half" if half else "unorm8", got[i], want)
+        if half:
+            assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
+        else:
+            assert r["max_lsb"] <= 1, r
 
 
 @pytest.mark.parametrize("content", ["structured", "random"])

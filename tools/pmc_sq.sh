@@ -12,7 +12,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
            "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
   rm -rf /tmp/sq_${TAG}_$i
-  rocprofv3 --pmc $SET --output-format csv -d /tmp/sq_${TAG}_$i -o pmc -- python bench.py --no-cpu --pmc off --steps 2 --warmup 1 --pairs 4 "$@" > "$OUT/sq_pass$i.log" 2>&1
+  rocprofv3 --pmc $SET --output-format csv -d /tmp/sq_${TAG}_$i -o pmc -- python bench.py --no-cpu --no-extras --no-verify --pmc off --steps 2 --warmup 1 --pairs 4 "$@" > "$OUT/sq_pass$i.log" 2>&1
   F=$(find /tmp/sq_${TAG}_$i -name '*counter_collection.csv' | head -1)
   [ -n "$F" ] && python - "$F" >> "$OUT/sq_counters.txt" <<'PY'
 import csv, sys, collections

@@ -7,10 +7,10 @@ TAG=${1:-run}; shift || true
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profile/$TAG
 rm -rf "$OUT" /tmp/prof_$TAG; mkdir -p "$OUT" /tmp/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -o kt -- python bench.py --no-cpu --pmc off "$@" > "$OUT/bench_under_kernel_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -o kt -- python bench.py --no-cpu --no-extras --no-verify --pmc off "$@" > "$OUT/bench_under_kernel_trace.log" 2>&1
 find /tmp/prof_$TAG/kt -name '*kernel_stats.csv' -exec cp {} "$OUT/kernel_stats.csv" \;
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$TAG/$C -o pmc -- python bench.py --no-cpu --pmc off "$@" --steps 2 --warmup 1 --pairs 4 > "$OUT/bench_under_$C.log" 2>&1
+  rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$TAG/$C -o pmc -- python bench.py --no-cpu --no-extras --no-verify --pmc off "$@" --steps 2 --warmup 1 --pairs 4 > "$OUT/bench_under_$C.log" 2>&1
   F=$(find /tmp/prof_$TAG/$C -name '*counter_collection.csv' | head -1)
   if [ -n "$F" ]; then
     python - "$F" "$C" > "$OUT/pmc_$C.txt" <<'PY'
