@@ -17,8 +17,8 @@ constexpr int kTileW = 32;  // output pixels per workgroup tile (two 16-px mask 
 constexpr int kTileH = 32;
 constexpr int kThreads = 256;
 constexpr int kLumPadRows = 5;    // rows past the EASU luma plane that the 4-rows-per-lane analysis sweep may read (allocated, never written)
-// dynamic LDS the fused kernel may ask for: the 160 KiB of a CU minus its static LDS (the near-tie lists)
-constexpr size_t kFusedLdsMax = 159 * 1024;
+// dynamic LDS the fused kernel may ask for: the 160 KiB of a CU minus its static LDS (row / column tables of stage 1, list counters: < 2 KiB)
+constexpr size_t kFusedLdsMax = 158 * 1024;
 #ifndef OVRFSR_FUSED_NT
 #define OVRFSR_FUSED_NT 256
 #endif
@@ -117,6 +117,8 @@ struct FusedArgs {
     uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launchers
     const uint32_t *tileList; // optional mask-sorted tile list (see EasuArgs)
     float tieHalfMin;         // near-tie guard of a half intermediate (see EasuArgs)
+    const BilinTap *bilX;     // [outW], [outH] column / row taps of the bilinear fallback (product build: groups outside the
+    const BilinTap *bilY;     // radius inside a tile that touches it take their texels from the LDS colour plane)
 };
 
 struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) minus the unused viewport fields

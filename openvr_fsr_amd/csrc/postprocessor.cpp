@@ -729,6 +729,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
     a.tilesY = (out.height + kTileH - 1) / kTileH;
     a.tileList = nullptr;
     a.tieHalfMin = TieHalfMin();
+    a.bilX = bilinDev_; a.bilY = bilinDev_ + outputWidth_;
     hipError_t e = hipSuccess;
     if (!tileListDev_) {
         e = launch_fused(cfg_.precision, (int)in.format, (int)IntermediateFormat(), (int)out.format, a, n, stream);
