@@ -422,7 +422,10 @@ def dominant_kernels(workload):
     return ["easu_fast_kernel"]
 
 
-PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]]
+PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"],
+              # instruction counts per category and waves: what tools/isa_costs.py turns into VALU issue cycles (roofline.valu.issue)
+              ["SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_VALU_TRANS_F32"]]
+PMC_FULL_NAMES = {}   # short kernel name -> set of full (demangled) names seen in the counter passes
 PMC_CHILD_PAIRS = 4
 
 
@@ -457,9 +460,10 @@ def pmc_counters(args, timeout_s=120):
                         continue
                     m = re.search(r"ovrfsr_\w+::(\w+)", k)
                     short = m.group(1) if m else k
+                    PMC_FULL_NAMES.setdefault(short, set()).add(k)
                     agg.setdefault(short, {}).setdefault(r.get("Counter_Name"), []).append(float(r.get("Counter_Value", 0)))
         except (subprocess.SubprocessError, OSError, ValueError):
-            failed = True   # this pass is lost; do not spend more wall time on a profiler that is not usable here
+            failed = len(agg) == 0   # the first pass is lost: do not spend more wall time on a profiler that is not usable here
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     if not agg:
@@ -487,6 +491,59 @@ def profile_traffic(workload, kernels, n_img):
         return int(sum(h["hbm_bytes_per_eye"] for h in hit) * n_img) if hit else None
     except (OSError, KeyError, ValueError):
         return None
+
+
+def issue_roof(pmc, kernels, scale, out_px, ms_dom, sclk_mhz):
+    """The roof these kernels sit on, from THIS run's counters and the shipped code objects: VALU issue cycles.
+    openvr_fsr_amd/kernel_issue_costs.json (tools/isa_costs.py, emitted by the build from llvm-objdump of the library) holds
+    every kernel's basic blocks with their instruction counts per issue class and the edges between them; how often each block
+    executes is bounded by linear programming from the per-wave instruction counts measured here (SQ_INSTS_VALU / LDS /
+    VMEM_RD / VMEM_WR [/ TRANS / SMEM / BRANCH / SALU] over SQ_WAVES) under flow conservation.  The result is an interval:
+      cycles_per_64px  issue cycles per 64 output pixels (class costs in true shader cycles: profiles/r04_valu_issue_rates.txt)
+      issue_frac       issue cycles x waves / (1024 SIMDs x measured sclk x kernel time): ~1 = the VALU issues back to back."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import isa_costs
+        doc = isa_costs.load()
+    except (OSError, ValueError, ImportError) as e:
+        return {"error": "no issue-cost table (%s): run __graft_entry__.build()" % e}
+    per_kernel, lo_sum, hi_sum = {}, 0.0, 0.0
+    for k in kernels:
+        v = pmc.get(k)
+        full = sorted(PMC_FULL_NAMES.get(k, ()))
+        if not v or len(full) != 1 or not v.get("SQ_WAVES") or not v.get("SQ_INSTS_VALU"):
+            per_kernel[k] = {"error": "counters or a unique instantiation missing", "instantiations": full}
+            continue
+        cfg = isa_costs.find_kernel(doc, full[0])
+        if cfg is None:
+            per_kernel[k] = {"error": "not in kernel_issue_costs.json", "name": full[0]}
+            continue
+        w = v["SQ_WAVES"]
+        pw = {"valu": v["SQ_INSTS_VALU"] / w}
+        for key, ctr in (("lds", "SQ_INSTS_LDS"), ("vmem_rd", "SQ_INSTS_VMEM_RD"), ("vmem_wr", "SQ_INSTS_VMEM_WR"), ("trans", "SQ_INSTS_VALU_TRANS_F32"),
+                         ("smem", "SQ_INSTS_SMEM"), ("branch", "SQ_INSTS_BRANCH"), ("salu", "SQ_INSTS_SALU")):
+            if ctr in v:
+                pw[key] = v[ctr] / w
+        b = isa_costs.issue_bounds(cfg, pw)
+        if b is None:
+            per_kernel[k] = {"error": "no block-execution profile fits the counters", "per_wave": {a: round(x, 3) for a, x in pw.items()}}
+            continue
+        waves = w * scale
+        lo_sum += b["lo"] * waves
+        hi_sum += b["hi"] * waves
+        per_kernel[k] = {"kernel": full[0], "waves_per_launch": int(waves), "valu_instr_per_wave": round(pw["valu"], 1),
+                         "issue_cycles_per_wave": [round(b["lo"], 1), round(b["hi"], 1)], "mean_cycles_per_valu_instr": [round(b["mean_cost_lo"], 3), round(b["mean_cost_hi"], 3)],
+                         "counters_used": b["constraints"], "tolerance": b["tolerance"], "blocks": len(cfg["blocks"])}
+    if hi_sum == 0.0:
+        return {"per_kernel": per_kernel}
+    out = {"cycles_per_64px": [round(lo_sum / (out_px / 64.0), 1), round(hi_sum / (out_px / 64.0), 1)], "per_kernel": per_kernel,
+           "class_costs_true_cycles": isa_costs.COST, "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
+           "method": "tools/isa_costs.py: CFG + per-class instruction counts from llvm-objdump of the shipped library; block executions bounded by LP from this run's "
+                     "per-wave counters under flow conservation (interval = every profile the counters allow)"}
+    if sclk_mhz:
+        cap = 1024.0 * sclk_mhz * 1e6 * ms_dom * 1e-3   # SIMD-cycles available in the launch
+        out["issue_frac"] = [round(lo_sum / cap, 3), round(hi_sum / cap, 3)]
+    return out
 
 
 def roofline(args, shard):
@@ -546,18 +603,23 @@ def roofline(args, shard):
                 if v.get("GRBM_GUI_ACTIVE"):   # SQ_ACTIVE_INST_* tick in quad-cycles; GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs
                     busy = round(4.0 * v["SQ_ACTIVE_INST_VALU"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 3)
             roof["valu"] = {"instr_per_64px": round(instr / (out_px / 64.0), 1), "lane_instr_per_s": round(lane_rate, 0),
-                            "peak": VALU_PEAK_LANE_INSTR, "frac": round(lane_rate / VALU_PEAK_LANE_INSTR, 4), "valu_active_ratio": busy,
+                            "lane_instr_peak_if_every_op_took_2_cycles": VALU_PEAK_LANE_INSTR,
+                            "instr_count_over_2cycle_peak": round(lane_rate / VALU_PEAK_LANE_INSTR, 4), "valu_active_ratio": busy,
                             "per_kernel_instr_per_64px": {k: round(v["SQ_INSTS_VALU"] * scale / (out_px / 64.0), 1) for k, v in hit.items()},
                             "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE pass of this run; "
                                       "valu_active_ratio = 4*SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs): NOT a fraction -- the quad-cycle counter counts every "
                                       "instruction's full issue time, so ops slower than 4 cycles push it past 1 (1.0-1.3 on these kernels = the VALU never idles); "
-                                      "peak = 1024 SIMD-32 x 32 lanes x 2.4 GHz"}
+                                      "instr_count_over_2cycle_peak is a COUNT ratio (1024 SIMD-32 x 32 lanes x 2.4 GHz if every op issued in 2 cycles; real ops "
+                                      "take 2.5-8), not a utilisation: the utilisation figure is valu.issue.issue_frac"}
+    if pmc and roof["valu"] is not None:
+        roof["valu"]["issue"] = issue_roof(pmc, kernels, scale, out_px, ms_dom, sclk_mhz)
     if roof["traffic"] is None:
         roof["traffic"] = profile_traffic(args.workload, kernels, n_img)
         if roof["traffic"] is not None:
             roof["traffic_source"] = "profiles/traffic_per_eye.json (committed rocprofv3 PMC summary; not re-measured in this run)"
-    roof["note"] = ("frac is against the HBM roof the contract names; the kernels are VALU-issue-bound on this chip "
-                    "(valu.valu_active_ratio >= 1), so valu.frac / valu.instr_per_64px are the figures that move with kernel work")
+    roof["note"] = ("frac is against the HBM roof the contract names; the kernels are VALU-issue-bound on this chip: valu.issue.issue_frac "
+                    "(issue cycles from the shipped ISA and this run's counters over SIMD-cycles at the measured sclk) is the utilisation of the "
+                    "roof that binds them, valu.instr_per_64px the figure that moves with kernel work")
     return roof
 
 

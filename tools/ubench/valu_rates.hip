@@ -6,6 +6,11 @@
 #include <vector>
 #include <string>
 
+// shader-clock ticks (s_memtime) and constant 100 MHz ticks (s_memrealtime) around the measured loop, one wave: the ratio is the
+// clock the loop actually ran at, so that the table can be stated in true cycles (the chip is power-managed: 2.1-2.4 GHz)
+__device__ unsigned long long g_ticks[2];
+#define OVR_T0 const unsigned long long ovr_c0 = clock64(), ovr_w0 = wall_clock64();
+#define OVR_T1 if (blockIdx.x == 0 && threadIdx.x == 0) { g_ticks[0] = clock64() - ovr_c0; g_ticks[1] = wall_clock64() - ovr_w0; }
 #define REP8(x) x x x x x x x x
 #define REP64(x) REP8(REP8(x))
 
@@ -19,8 +24,8 @@
         __syncthreads();                                                                          \
         unsigned addr = (threadIdx.x * 16) & 8191;                                                \
         (void)addr;                                                                               \
-        for (int i = 0; i < iters; ++i) { REP8(BODY) }                                             \
-        out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7; \
+        OVR_T0 for (int i = 0; i < iters; ++i) { REP8(BODY) }                                             \
+        OVR_T1 out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7; \
     }
 
 // 8 independent instructions per BODY -> 64 per loop iteration
@@ -78,9 +83,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));
         float s = seed + threadIdx.x;                                                             \
         float2v p0 = {s, s + 1}, p1 = {s + 2, s + 3}, p2 = {s + 4, s + 5}, p3 = {s + 6, s + 7}, p4 = {s + 8, s + 9}, p5 = {s + 10, s + 11}, p6 = {s + 12, s + 13}, p7 = {s + 14, s + 15}; \
         float2v q0 = p0 * .5f, q1 = p1 * .5f, q2 = p2 * .5f, q3 = p3 * .5f, q4 = p4 * .5f, q5 = p5 * .5f, q6 = p6 * .5f, q7 = p7 * .5f; \
-        for (int i = 0; i < iters; ++i) { REP8(BODY) }                                             \
+        OVR_T0 for (int i = 0; i < iters; ++i) { REP8(BODY) }                                             \
         float2v r = p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7 + q0 + q1 + q2 + q3 + q4 + q5 + q6 + q7;  \
-        out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y;                                           \
+        OVR_T1 out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y;                                           \
     }
 
 KERNEL(k_fma_f32, V8("v_fma_f32"))
@@ -183,8 +188,8 @@ __global__ __launch_bounds__(256) void k_cndmask_sgpr(float *out, int iters, flo
     float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
     float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * .5f, b3 = a3 * .5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;
     unsigned long long m = __builtin_amdgcn_ballot_w64(seed + threadIdx.x > 40.f);
-    for (int i = 0; i < iters; ++i) { REP8(VCNDS8) }
-    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7;
+    OVR_T0 for (int i = 0; i < iters; ++i) { REP8(VCNDS8) }
+    OVR_T1 out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7;
 }
 #define VDPP8(CTRL)                                                            \
     asm volatile("v_mov_b32_dpp %0, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "+v"(a0) : "v"(b0)); \
@@ -251,8 +256,8 @@ PKERNEL(k_pk_add_f32, P4_2("v_pk_add_f32"))
         unsigned addr = (threadIdx.x & 63) * STRIDE + (threadIdx.x >> 6) * 4096;                    \
         TYPE r0, r1, r2, r3, r4, r5, r6, r7;                                                       \
         float acc = 0;                                                                            \
-        for (int i = 0; i < iters; ++i) { REP8(L8(INS, 0)) acc += ((float *)&r0)[0] + ((float *)&r7)[0]; } \
-        out[blockIdx.x * 256 + threadIdx.x] = acc + ((float *)&r1)[0] + ((float *)&r2)[0] + ((float *)&r3)[0] + ((float *)&r4)[0] + ((float *)&r5)[0] + ((float *)&r6)[0]; \
+        OVR_T0 for (int i = 0; i < iters; ++i) { REP8(L8(INS, 0)) acc += ((float *)&r0)[0] + ((float *)&r7)[0]; } \
+        OVR_T1 out[blockIdx.x * 256 + threadIdx.x] = acc + ((float *)&r1)[0] + ((float *)&r2)[0] + ((float *)&r3)[0] + ((float *)&r4)[0] + ((float *)&r5)[0] + ((float *)&r6)[0]; \
     }
 typedef float float4v __attribute__((ext_vector_type(4)));
 LKERNEL(k_ds_read_b32, float, "ds_read_b32", 4)
@@ -267,6 +272,19 @@ __global__ void k_probe_cvt(float *out)
     for (int i = 0; i < 8; ++i) { unsigned r = 0; asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(r) : "v"(vals[i])); out[i] = (float)r; }
 }
 typedef void (*kern_t)(float *, int, float);
+
+// Which clock do the figures below refer to?  One wave of a sustained v_fma loop reads s_memtime (shader-clock counter) and
+// s_memrealtime (constant 100 MHz) around the loop: their ratio x 100 MHz is the shader clock this load actually runs at.
+__global__ __launch_bounds__(256) void k_clock_probe(float *out, unsigned long long *ticks, int iters, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * .5f, b3 = a3 * .5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) { REP8(V8("v_fma_f32")) }
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ticks[0] = c1 - c0; ticks[1] = w1 - w0; }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7;
+}
 
 static double run(kern_t k, float *d, int iters, int blocks)
 {
@@ -314,13 +332,31 @@ int main()
         {"v_mov_b32_dpp wave_shr:1", k_mov_dpp_wave_shr, 64}, {"v_add_f32_dpp row_shr:1", k_add_f32_dpp, 64}, {"ds_bpermute_b32 (+wait)", k_ds_bpermute, 64},
         {"ds_read_b32", k_ds_read_b32, 64}, {"ds_read_b64", k_ds_read_b64, 64}, {"ds_read_b128", k_ds_read_b128, 64},
     };
+    {
+        unsigned long long *dt, ht[2] = {0, 0};
+        hipMalloc(&dt, 16);
+        int wall_khz = 0;
+        hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+        for (int rep = 0; rep < 3; ++rep) { // ~25 ms each: long enough for the power controller to settle
+            hipLaunchKernelGGL(k_clock_probe, dim3(blocks), dim3(256), 0, 0, d, dt, 40000, 1.0f);
+            hipDeviceSynchronize();
+            hipMemcpy(ht, dt, 16, hipMemcpyDeviceToHost);
+            printf("clock probe (sustained v_fma_f32, 8 waves/SIMD): s_memtime %llu ticks, s_memrealtime %llu ticks (wall clock rate %d kHz) -> ratio %.4f = %.1f MHz if s_memtime is the shader clock\n",
+                   ht[0], ht[1], wall_khz, (double)ht[0] / (double)ht[1], (double)ht[0] / (double)ht[1] * wall_khz * 1e-3);
+        }
+        hipFree(dt);
+    }
     const int iters = 4000;
     for (auto &k : ks) {
         double ms = run(k.k, d, iters, blocks);
         // per SIMD: 8 waves each issuing iters*per_iter instructions
         double instr_per_simd = 8.0 * iters * k.per_iter;
         double cyc = ms * 1e-3 * ghz * 1e9 / instr_per_simd;
-        printf("%-22s %8.3f ms  %6.2f cycles / wave-instruction / SIMD (at %.2f GHz nominal)\n", k.n, ms, cyc, ghz);
+        unsigned long long ht[2] = {0, 1};
+        hipMemcpyFromSymbol(ht, HIP_SYMBOL(g_ticks), sizeof(ht));
+        const double mhz = (double)ht[0] / (double)ht[1] * 100.0; // s_memrealtime: 100 MHz
+        printf("%-22s %8.3f ms  %6.2f cycles / wave-instruction / SIMD (at %.2f GHz nominal)  | ran at %6.1f MHz -> %5.2f true cycles\n", k.n, ms, cyc, ghz, mhz,
+               cyc * mhz / (ghz * 1e3));
     }
     hipLaunchKernelGGL(k_probe_cvt, dim3(1), dim3(1), 0, 0, d);
     float h[8]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
