@@ -532,6 +532,7 @@ def issue_roof(pmc, kernels, scale, out_px, ms_dom, sclk_mhz):
         lo_sum += b["lo"] * waves
         hi_sum += b["hi"] * waves
         per_kernel[k] = {"kernel": full[0], "waves_per_launch": int(waves), "valu_instr_per_wave": round(pw["valu"], 1),
+                         "per_wave_counters": {a: round(x, 4) for a, x in pw.items()},
                          "issue_cycles_per_wave": [round(b["lo"], 1), round(b["hi"], 1)], "mean_cycles_per_valu_instr": [round(b["mean_cost_lo"], 3), round(b["mean_cost_hi"], 3)],
                          "counters_used": b["constraints"], "tolerance": b["tolerance"], "blocks": len(cfg["blocks"])}
     if hi_sum == 0.0:

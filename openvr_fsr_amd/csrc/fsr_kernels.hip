@@ -188,7 +188,11 @@ hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const Fu
     const bool strict = prec == PREC_FP32_STRICT;
     if (!strict && easu_fast_pitch(a.cellsW) == 0) return hipErrorInvalidValue;
     const dim3 grid(a.tileList ? nTiles : a.tilesX * a.tilesY, 1, batch);
-    const size_t lds = fused_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH);
+    // OVRFSR_FUSED_LDS_PAD=<bytes> (diagnostic): extra dynamic LDS nobody touches -> fewer workgroups per CU; measures how the kernel's
+    // throughput follows its occupancy (profiles/r04_fused_variants.txt) before anyone rebuilds its planes to gain a workgroup
+    static const size_t pad = [] { const char *e = std::getenv("OVRFSR_FUSED_LDS_PAD"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 0); }();
+    size_t lds = fused_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH) + pad;
+    if (lds > kFusedLdsMax) lds = kFusedLdsMax;
     OVRFSR_DISPATCH_FMT3(fused_go, mid_fmt, strict, a, grid, lds, s)
 }
 

@@ -9,6 +9,8 @@ src, dst = os.path.join(root, "gpurun_out", "profile", tag), os.path.join(root, 
 os.makedirs(dst, exist_ok=True)
 for f in ("kernel_stats.csv", "pmc_FETCH_SIZE.txt", "pmc_WRITE_SIZE.txt", "traffic_per_eye.json"):
     shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+if os.path.exists(os.path.join(src, "issue_roof.txt")):   # per-wave instruction counters + the VALU issue-cycle interval (tools/isa_costs.py)
+    shutil.copy(os.path.join(src, "issue_roof.txt"), os.path.join(dst, "issue_roof.txt"))
 # keep only the rows of our kernels + the header in the committed kernel stats
 rows = open(os.path.join(dst, "kernel_stats.csv")).read().splitlines()
 open(os.path.join(dst, "kernel_stats.csv"), "w").write("\n".join([rows[0]] + [r for r in rows[1:] if "ovrfsr" in r]) + "\n")

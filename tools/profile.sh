@@ -25,6 +25,32 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
 PY
   fi
 done
+# per-wave instruction counters -> VALU issue-cycle interval of every kernel (tools/isa_costs.py; what bench.py reports as roofline.valu.issue)
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU_TRANS_F32 --output-format csv -d /tmp/prof_$TAG/issue -o pmc -- python bench.py --no-cpu --no-extras --no-verify --pmc off "$@" --steps 2 --warmup 1 --pairs 4 > "$OUT/bench_under_issue_counters.log" 2>&1
+F=$(find /tmp/prof_$TAG/issue -name '*counter_collection.csv' | head -1)
+[ -n "$F" ] && python - "$F" > "$OUT/issue_roof.txt" <<'PY'
+import csv, sys, collections, os
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "tools"))
+import isa_costs
+doc = isa_costs.load()
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(sys.argv[1])):
+    if "ovrfsr" in r.get("Kernel_Name", ""):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("# per-wave instruction counters (rocprofv3 --pmc, launches of 8 eye images) and the VALU issue-cycle interval they imply (tools/isa_costs.py)")
+print("# class costs (true cycles):", isa_costs.COST)
+for k, cs in agg.items():
+    m = {c: sum(v) / len(v) for c, v in cs.items()}
+    w = m.get("SQ_WAVES")
+    cfg = isa_costs.find_kernel(doc, k)
+    if not w or cfg is None:
+        continue
+    pw = {a: m[c] / w for a, c in (("valu", "SQ_INSTS_VALU"), ("lds", "SQ_INSTS_LDS"), ("vmem_rd", "SQ_INSTS_VMEM_RD"), ("vmem_wr", "SQ_INSTS_VMEM_WR"),
+                                   ("trans", "SQ_INSTS_VALU_TRANS_F32"), ("smem", "SQ_INSTS_SMEM"), ("salu", "SQ_INSTS_SALU")) if c in m}
+    b = isa_costs.issue_bounds(cfg, pw)
+    print("%s\n   waves %d  per wave: %s\n   issue cycles per wave: %s" % (k, w, " ".join("%s=%.3f" % kv for kv in pw.items()),
+          "[%.1f, %.1f] (mean %.3f..%.3f cycles per VALU instruction; counters used: %s, tolerance %.2f)" % (b["lo"], b["hi"], b["mean_cost_lo"], b["mean_cost_hi"], ",".join(b["constraints"]), b["tolerance"]) if b else "no profile fits"))
+PY
 # HBM bytes per eye image of each ovrfsr kernel: WRITE_SIZE (KiB, calibrated 1.0 on 4-B/lane stores) +
 # 2 x FETCH_SIZE (KiB; gfx950 rocprofv3 reports half the bytes of a coalesced read -- MI355X_MICROARCH.md, confirmed
 # here: RCAS reads exactly its input).  The PMC passes ran with --pairs 4 -> 8 eye images per launch.
