@@ -7,7 +7,7 @@
  *   gcc -std=c11 -O2 -pthread -D_POSIX_C_SOURCE=200809L -D__HIP_PLATFORM_AMD__ examples/bench_node.c -Iinclude -I/opt/rocm/include \
  *       -Lopenvr_fsr_amd -lopenvr_fsr_amd -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,'$ORIGIN/../openvr_fsr_amd' \
  *       -Wl,-rpath,/opt/rocm/lib -o examples/bench_node          (__graft_entry__.build() does this)
- *   examples/bench_node [--gpus N] [--pairs P] [--steps K] [--warmup W] [--radius R] [--oversubscribe]
+ *   examples/bench_node [--gpus N] [--pairs P] [--steps K] [--warmup W] [--radius R] [--fused] [--oversubscribe]
  *
  * Workload: BASELINE C2's shape (1683x1869 -> 2244x2492 RGBA8, EASU -> UNORM8 -> RCAS, sharpness 0.9); the eye images are a
  * cheap deterministic pattern generated on the host once per device (gradients, a checker, a diagonal ramp, hashed noise),
@@ -27,7 +27,7 @@
 enum { IN_W = 1683, IN_H = 1869, OUT_W = 2244, OUT_H = 2492 };
 
 typedef struct {
-    int index, device, pairs, steps, warmup;
+    int index, device, pairs, steps, warmup, fused;
     float radius;
     pthread_barrier_t *gate;
     double t_start, t_end; /* host seconds around the timed region */
@@ -100,6 +100,7 @@ static void *run_shard(void *arg)
         ovrfsr_config cfg;
         ovrfsr_config_default(&cfg);
         cfg.fsr_enabled = 1; cfg.sharpness = 0.9f; cfg.radius = s->radius; cfg.out_width = OUT_W; cfg.out_height = OUT_H;
+        if (s->fused) cfg.fused = 1; /* one launch, intermediate in LDS: its raised dynamic-LDS attribute is per device */
         const int rc = ovrfsr_create(s->device, &cfg, &ctx);
         if (rc != OVRFSR_OK) FAIL(s, "ovrfsr_create(%d): status %d", s->device, rc);
     }
@@ -133,16 +134,17 @@ static void *run_shard(void *arg)
 
 int main(int argc, char **argv)
 {
-    int gpus = 1, pairs = 64, steps = 20, warmup = 5, oversubscribe = 0;
+    int gpus = 1, pairs = 64, steps = 20, warmup = 5, oversubscribe = 0, fused = 0;
     float radius = 2.0f;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--oversubscribe")) oversubscribe = 1;
+        else if (!strcmp(argv[i], "--fused")) fused = 1;
         else if (i + 1 < argc && !strcmp(argv[i], "--gpus")) gpus = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--pairs")) pairs = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--steps")) steps = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--warmup")) warmup = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--radius")) radius = (float)atof(argv[++i]);
-        else { fprintf(stderr, "usage: %s [--gpus N] [--pairs P] [--steps K] [--warmup W] [--radius R] [--oversubscribe]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s [--gpus N] [--pairs P] [--steps K] [--warmup W] [--radius R] [--fused] [--oversubscribe]\n", argv[0]); return 2; }
     }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
@@ -154,7 +156,7 @@ int main(int argc, char **argv)
     shard_t *sh = (shard_t *)calloc((size_t)gpus, sizeof *sh);
     pthread_t *th = (pthread_t *)calloc((size_t)gpus, sizeof *th);
     for (int i = 0; i < gpus; ++i) {
-        sh[i].index = i; sh[i].device = i % count; sh[i].pairs = pairs; sh[i].steps = steps; sh[i].warmup = warmup; sh[i].radius = radius;
+        sh[i].index = i; sh[i].device = i % count; sh[i].pairs = pairs; sh[i].steps = steps; sh[i].warmup = warmup; sh[i].radius = radius; sh[i].fused = fused;
         sh[i].gate = &gate;
         pthread_create(&th[i], NULL, run_shard, &sh[i]);
     }

@@ -175,3 +175,33 @@ def test_bgra8_input_equals_rgba8(gpu, nis, radius, prec):
         i = image_of(torch.from_numpy(imgs[0]).cuda())
         pp._check(pp._lib.ovrfsr_apply(pp._ctx, 0, C.byref(i), None, C.byref(o), None))   # BGRA8 as a destination
     pp.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# RGBA16F with values above 1 (HDR): the half near-tie guard's band follows the binade (round 4)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scale", [1.0, 6.0, 40.0])
+def test_half_pipeline_hdr_values(gpu, scale):
+    """EASU -> half intermediate -> RCAS on RGBA16F images whose values reach `scale`.  The strict build is bit-exact against the
+    oracle at every magnitude (the filters are homogeneous only up to RCAS's peak constant, so this is a real case, not a rescaled
+    one); the product build's error stays within 1e-3 RELATIVE to the image's magnitude -- the re-association error it guards
+    against is relative, and since round 4 so is the band of the half near-tie guard (rounds 2-3 used an absolute 2^-17: no cover
+    at all above 2.0, where the half spacing outgrows it)."""
+    from tests.util import run_gpu
+    iw, ih, ow, oh = 237, 180, 316, 240
+    base = synth.structured_u8(iw, ih, 91).astype(np.float32) / 255.0
+    imgh = (base * np.float32(scale)).astype(np.float16)
+    imgh[..., 3] = np.float16(1.0)
+    centre, rad = O.mask_constants(ow, oh, 0.6)
+    e = O.easu(imgh.astype(np.float32), ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
+    want = O.rcas(e.astype(np.float16).astype(np.float32), O.rcas_con(0.9), centre, rad).astype(np.float16)
+    kw = dict(sharpness=0.9, radius=0.6)
+    got = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, **kw)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), scale
+    for fused in (-1, 0, 1):
+        got = run_gpu(imgh, ow, oh, np.float16, precision=FP32, fused=fused, **kw).astype(np.float32)
+        w32 = want.astype(np.float32)
+        ok = np.isfinite(w32)
+        err = np.abs(got[ok] - w32[ok])
+        assert err.max() <= 1e-3 * max(1.0, scale), (scale, fused, float(err.max()))
+        assert np.array_equal(np.isfinite(got), ok)

@@ -689,6 +689,11 @@ def test_c_node_driver(gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "eye-pairs/s" and d["value"] > 0
     assert len(d["config"]["per_device_ms_per_step"]) == 2 and all(m > 0 for m in d["config"]["per_device_ms_per_step"])
     assert d["config"]["pairs_per_gpu_per_step"] == 2 and "oversubscribed" in d["config"]
+    # the fused kernel (cfg.fused = 1) raises its dynamic-LDS attribute per (kernel, device): two ctxs, one process, masked tiles
+    r = subprocess.run([exe, "--gpus", "2", "--oversubscribe", "--pairs", "2", "--steps", "2", "--warmup", "1", "--fused", "--radius", "0.5"],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["value"] > 0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -787,3 +792,19 @@ def test_two_ctxs_on_two_host_threads(gpu):
     for ci in range(2):
         for i in range(len(imgs)):
             assert np.array_equal(got[ci][i], want[ci][i]), (ci, i)
+
+
+def test_clock_probe_reports_the_shader_clock(gpu):
+    """ovrfsr_debug_clock_probe (bench.py's roofline.sclk_mhz): the ratio of the shader-clock counter to the 100 MHz counter over a
+    2 ms sleep is a plausible gfx950 clock; bad arguments are rejected."""
+    import ctypes as C
+    import torch
+    import openvr_fsr_amd as A
+    lib = A.library()
+    ticks = torch.zeros(2, dtype=torch.int64, device="cuda")
+    assert lib.ovrfsr_debug_clock_probe(0, C.c_void_p(ticks.data_ptr()), 2000, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    c, w = ticks.cpu().tolist()
+    assert 190000 <= w <= 400000, w                    # ~2 ms of a 100 MHz counter
+    assert 100.0 <= c / w * 100.0 <= 3000.0, (c, w)    # idle clocks can be low; never above the 2.4 GHz peak by much
+    assert lib.ovrfsr_debug_clock_probe(0, None, 2000, None) == 1 and lib.ovrfsr_debug_clock_probe(0, C.c_void_p(ticks.data_ptr()), 0, None) == 1

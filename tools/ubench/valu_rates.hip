@@ -103,6 +103,21 @@ KERNEL(k_cvt_f32_f16, V8_1("v_cvt_f32_f16"))
 KERNEL(k_cvt_f16_f32, V8_1("v_cvt_f16_f32"))
 KERNEL(k_cvt_f32_ubyte0, V8_1("v_cvt_f32_ubyte0"))
 KERNEL(k_rcp_f32, V8_1("v_rcp_f32"))
+
+// Are the class costs additive when the classes are interleaved, as they are in real kernels?  Eight independent instructions per
+// BODY as above, mixed: if a mix costs less than the sum of its parts the classes overlap (a transcendental among ordinary VALU
+// work issues in ~4 cycles; only back-to-back transcendentals pay 8), and tools/isa_costs.py must price them accordingly.
+#define F1(R, B) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(R) : "v"(B));
+#define T1(R, B) asm volatile("v_rcp_f32 %0, %1" : "+v"(R) : "v"(B));
+#define S1(R, B) asm volatile("v_min3_f32 %0, %0, %1, %0" : "+v"(R) : "v"(B));
+#define MIX_1T_7F T1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) F1(a4, b4) F1(a5, b5) F1(a6, b6) F1(a7, b7)
+#define MIX_2T_6F T1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) T1(a4, b4) F1(a5, b5) F1(a6, b6) F1(a7, b7)
+#define MIX_1T_7S T1(a0, b0) S1(a1, b1) S1(a2, b2) S1(a3, b3) S1(a4, b4) S1(a5, b5) S1(a6, b6) S1(a7, b7)
+#define MIX_4S_4F S1(a0, b0) F1(a1, b1) S1(a2, b2) F1(a3, b3) S1(a4, b4) F1(a5, b5) S1(a6, b6) F1(a7, b7)
+KERNEL(k_mix_1t_7f, MIX_1T_7F)
+KERNEL(k_mix_2t_6f, MIX_2T_6F)
+KERNEL(k_mix_1t_7s, MIX_1T_7S)
+KERNEL(k_mix_4s_4f, MIX_4S_4F)
 KERNEL(k_rcp_f16, V8_1("v_rcp_f16"))
 KERNEL(k_sub_u32, V8_2("v_sub_u32"))
 KERNEL(k_lshrrev, V8_2("v_lshrrev_b32"))
@@ -319,7 +334,8 @@ int main()
         {"v_fma_mix_f32", k_fma_mix_f32, 64}, {"v_fma_mixlo_f16", k_fma_mixlo_f16, 64}, {"v_dot2_f32_f16", k_dot2_f32_f16, 64},
         {"v_cvt_f32_f16", k_cvt_f32_f16, 64}, {"v_cvt_f16_f32", k_cvt_f16_f32, 64}, {"v_cvt_pkrtz_f16_f32", k_cvt_pkrtz, 64},
         {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte0, 64},
-        {"v_rcp_f32", k_rcp_f32, 64}, {"v_rcp_f16", k_rcp_f16, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_lshrrev_b32", k_lshrrev, 64},
+        {"v_rcp_f32", k_rcp_f32, 64}, {"mix 1 rcp + 7 fma (per 8)", k_mix_1t_7f, 64}, {"mix 2 rcp + 6 fma (per 8)", k_mix_2t_6f, 64},
+        {"mix 1 rcp + 7 min3 (per 8)", k_mix_1t_7s, 64}, {"mix 4 min3 + 4 fma (per 8)", k_mix_4s_4f, 64}, {"v_rcp_f16", k_rcp_f16, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_lshrrev_b32", k_lshrrev, 64},
         {"v_min_u32", k_min_u32, 64}, {"v_max_i32", k_max_i32, 64}, {"v_min3_u32", k_min3_u32, 64}, {"v_max_f32", k_max_f32, 64}, {"v_max3_f32", k_max3_f32, 64},
         {"v_and_b32", k_and_b32, 64}, {"v_or_b32", k_or_b32, 64}, {"v_lshl_or_b32", k_lshl_or_b32, 64}, {"v_lshl_add_u32", k_lshl_add_u32, 64},
         {"v_add3_u32", k_add3_u32, 64}, {"v_perm_b32", k_perm_b32, 64}, {"v_bfe_u32", k_bfe_u32, 64}, {"v_cvt_pk_u8_f32", k_cvt_pk_u8_f32, 64},
