@@ -372,32 +372,6 @@ def time_events(fn, iters, stream):
     return s.elapsed_time(e) / iters
 
 
-def time_events_probed(fn, iters, stream, shard, probe_us=6000):
-    """time_events plus the shader clock the chip sustained meanwhile: while the timed launches execute, ONE sleeping wave on a side
-    stream (ovrfsr_debug_clock_probe) compares the shader-clock counter with the constant 100 MHz counter for `probe_us`.
-    Returns (ms per call, MHz or None)."""
-    import ctypes as C
-    dev = shard.dev
-    lib = shard.A.library()
-    ticks = torch.zeros(2, dtype=torch.int64, device=dev)
-    side = torch.cuda.Stream(device=dev)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fn(); fn()
-    torch.cuda.synchronize(dev)
-    s.record(stream)
-    rc = -1
-    for i in range(iters):
-        fn()
-        if i == 0:   # the launches are asynchronous: the probe starts while the first of them executes and sleeps through the next ones
-            rc = lib.ovrfsr_debug_clock_probe(shard.device_index, C.c_void_p(ticks.data_ptr()), int(probe_us), C.c_void_p(side.cuda_stream))
-    e.record(stream)
-    e.synchronize()
-    side.synchronize()
-    t = ticks.cpu().tolist()
-    mhz = (t[0] / t[1] * 100.0) if rc == 0 and t[1] > 0 else None
-    return s.elapsed_time(e) / iters, mhz
-
-
 def usable_cores():
     """CPUs this process may actually use: affinity mask, capped by the container's cgroup CPU quota (cpu.max) --
     a 256-thread host with a 16-CPU quota has 16, and running 256 OpenMP threads there is slower than 16."""
@@ -566,7 +540,9 @@ def issue_roof(pmc, kernels, scale, out_px, ms_dom, sclk_mhz):
     out = {"cycles_per_64px": [round(lo_sum / (out_px / 64.0), 1), round(hi_sum / (out_px / 64.0), 1)], "per_kernel": per_kernel,
            "class_costs_true_cycles": isa_costs.COST, "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
            "method": "tools/isa_costs.py: CFG + per-class instruction counts from llvm-objdump of the shipped library; block executions bounded by LP from this run's "
-                     "per-wave counters under flow conservation (interval = every profile the counters allow)"}
+                     "per-wave counters under flow conservation (interval = every profile the counters allow)",
+           "model_error": "class costs are those of homogeneous instruction streams, added up; mixed streams measured in profiles/r04_valu_issue_rates.txt cost "
+                          "0.69-0.81 (fast+slow alternating) to 1.18 (fast+packed) of the sum, an EASU-shaped mix 1.06: read 0.9-1.1 as 'issues back to back'"}
     if sclk_mhz:
         cap = 1024.0 * sclk_mhz * 1e6 * ms_dom * 1e-3   # SIMD-cycles available in the launch
         out["issue_frac"] = [round(lo_sum / cap, 3), round(hi_sum / cap, 3)]
@@ -589,19 +565,20 @@ def roofline(args, shard):
     if single_pass:
         # masked / NIS / sharpen-only: the step IS the kernel (plus its concurrent companions when masked)
         with sclk:
-            ms_dom, probe_mhz = time_events_probed(shard.step, max(iters, 10), stream, shard)
+            ms_dom = time_events(shard.step, max(iters, 10), stream)
         dom_bytes, out_px = algo_bytes_eye * n_img, outW * outH * n_img
     else:
         # dominant kernel of the two-pass pipeline: EASU -- launched alone over the same batch
         kw = dict(shard.cfg_kw, stage_mask=1)
         pe = A.PostProcessor(cfg=A.Config.default(**kw), device=shard.device_index)
         with sclk:
-            ms_dom, probe_mhz = time_events_probed(lambda: pe.apply_batch(shard.texs, shard.outs, first_eye=A.EYE_LEFT, alternate_eyes=True, shared=shard.shared),
-                                                   max(iters, 10), stream, shard)
+            ms_dom = time_events(lambda: pe.apply_batch(shard.texs, shard.outs, first_eye=A.EYE_LEFT, alternate_eyes=True, shared=shard.shared),
+                                 max(iters, 10), stream)
         pe.close()
         dom_bytes, out_px = bpp * (inW * inH + outW * outH) * n_img, outW * outH * n_img
-    smi_mhz = sclk.mean_mhz()
-    sclk_mhz = probe_mhz or smi_mhz   # the in-kernel counter ratio is the measurement; the SMI reading (a firmware average) is kept beside it
+    # (an in-kernel probe -- one sleeping wave on a side stream comparing s_memtime with the 100 MHz counter -- was tried in round 4:
+    # a second active hardware queue slows the timed kernel by 30-45 %, so the clock it reads is not the clock of the undisturbed run)
+    sclk_mhz = sclk.mean_mhz()
     ach = dom_bytes / (ms_dom * 1e-3) / 1e9
     pipe = algo_bytes_eye * n_img / (ms_step * 1e-3) / 1e9
     copy_gbps = copy_ceiling_gbps(dev)
@@ -611,9 +588,7 @@ def roofline(args, shard):
             "copy_ceiling": round(copy_gbps, 1), "frac_of_copy": round(ach / copy_gbps, 4),
             "pipeline_ms_per_step_events": round(ms_step, 4), "pipeline_achieved_GBps": round(pipe, 1),
             "pipeline_frac": round(pipe / HBM_PEAK_GBPS, 4), "binding_roof": "valu_issue", "valu": None,
-            "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None,
-            "sclk_source": "s_memtime / s_memrealtime over 6 ms in a sleeping wave beside the timed kernel (ovrfsr_debug_clock_probe)" if probe_mhz else sclk.source,
-            "sclk_smi_mhz": round(smi_mhz, 1) if smi_mhz else None, "sclk_smi_samples": len(sclk.samples)}
+            "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_source": sclk.source, "sclk_samples": len(sclk.samples)}
     pmc = pmc_counters(args) if args.pmc == "auto" else None
     if pmc:
         child_img = images_per_pair(args.workload) * PMC_CHILD_PAIRS

@@ -243,12 +243,6 @@ OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_conf
 /* Stand-in for the F7 capture (PostProcessor.cpp:640-657): dump a device image as a binary PPM. */
 OVRFSR_API int ovrfsr_save_ppm(const ovrfsr_image *img, const char *path, void *stream);
 
-/* Measurement aid, not part of the reference's surface: launches ONE wave on `stream` that sleeps for `microseconds` of the constant
- * 100 MHz counter and stores {shader-clock ticks, 100 MHz ticks} elapsed meanwhile into device_ticks[0..1] (device memory): their
- * ratio x 100 MHz is the shader clock the chip sustains under whatever else is running.  bench.py launches it on a side stream
- * beside the timed kernel to turn issue cycles into a utilisation (roofline.valu.issue). */
-OVRFSR_API int ovrfsr_debug_clock_probe(int device, uint64_t *device_ticks, uint32_t microseconds, void *stream);
-
 OVRFSR_API uint32_t ovrfsr_abi_version(void);
 
 #ifdef __cplusplus

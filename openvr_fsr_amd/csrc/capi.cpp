@@ -7,7 +7,6 @@
 #include <memory>
 #include <new>
 #include "postprocessor.hpp"
-#include "fsr_launch.h"
 #include "nis_tables.h"
 
 struct ovrfsr_ctx {
@@ -43,17 +42,6 @@ constexpr uint32_t kMaxExtent = 16384; // same limit CheckImage puts on caller i
 extern "C" {
 
 OVRFSR_API uint32_t ovrfsr_abi_version(void) { return OVRFSR_ABI_VERSION; }
-
-OVRFSR_API int ovrfsr_debug_clock_probe(int device, uint64_t *device_ticks, uint32_t microseconds, void *stream)
-{
-    if (!device_ticks || microseconds == 0 || microseconds > 1000000u) return OVRFSR_ERR_INVALID_ARGUMENT;
-    int prev = -1;
-    (void)hipGetDevice(&prev);
-    if (hipSetDevice(device) != hipSuccess) return OVRFSR_ERR_NO_DEVICE;
-    const hipError_t e = ovrfsr::launch_clock_probe(reinterpret_cast<unsigned long long *>(device_ticks), microseconds, static_cast<hipStream_t>(stream));
-    if (prev >= 0) (void)hipSetDevice(prev);
-    return e == hipSuccess ? OVRFSR_OK : OVRFSR_ERR_HIP;
-}
 
 OVRFSR_API void ovrfsr_config_default(ovrfsr_config *cfg)
 {

@@ -294,27 +294,6 @@ hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t s
     return hipGetLastError();
 }
 
-// Measurement aid (ovrfsr_debug_clock_probe): one wave sleeps for `ticks100MHz` ticks of the constant 100 MHz counter
-// (s_memrealtime) and reports how far the shader-clock counter (s_memtime) advanced meanwhile: their ratio x 100 MHz is the shader
-// clock the chip runs at while whatever else is resident executes.  No VALU work, no LDS: it fits beside any kernel.
-__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *out, unsigned long long ticks100MHz)
-{
-    const unsigned long long w0 = wall_clock64(), c0 = clock64();
-    unsigned long long w1 = w0;
-    while (w1 - w0 < ticks100MHz) {
-        __builtin_amdgcn_s_sleep(16);
-        w1 = wall_clock64();
-    }
-    const unsigned long long c1 = clock64();
-    if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; }
-}
-
-hipError_t launch_clock_probe(unsigned long long *out, uint32_t microseconds, hipStream_t s)
-{
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, s, out, (unsigned long long)microseconds * 100ull);
-    return hipGetLastError();
-}
-
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
     EasuArgs a = a_in;

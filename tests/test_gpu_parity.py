@@ -793,18 +793,3 @@ def test_two_ctxs_on_two_host_threads(gpu):
         for i in range(len(imgs)):
             assert np.array_equal(got[ci][i], want[ci][i]), (ci, i)
 
-
-def test_clock_probe_reports_the_shader_clock(gpu):
-    """ovrfsr_debug_clock_probe (bench.py's roofline.sclk_mhz): the ratio of the shader-clock counter to the 100 MHz counter over a
-    2 ms sleep is a plausible gfx950 clock; bad arguments are rejected."""
-    import ctypes as C
-    import torch
-    import openvr_fsr_amd as A
-    lib = A.library()
-    ticks = torch.zeros(2, dtype=torch.int64, device="cuda")
-    assert lib.ovrfsr_debug_clock_probe(0, C.c_void_p(ticks.data_ptr()), 2000, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
-    torch.cuda.synchronize()
-    c, w = ticks.cpu().tolist()
-    assert 190000 <= w <= 400000, w                    # ~2 ms of a 100 MHz counter
-    assert 100.0 <= c / w * 100.0 <= 3000.0, (c, w)    # idle clocks can be low; never above the 2.4 GHz peak by much
-    assert lib.ovrfsr_debug_clock_probe(0, None, 2000, None) == 1 and lib.ovrfsr_debug_clock_probe(0, C.c_void_p(ticks.data_ptr()), 0, None) == 1

@@ -21,12 +21,19 @@ is a linear system; `issue_bounds()` minimises and maximises  sum_b x_b * (issue
 The result is an INTERVAL [lo, hi] of VALU issue cycles per wave that every execution profile consistent with the counters must
 lie in -- narrow when the alternatives the counters cannot tell apart have similar instruction mixes, which is the case here.
 
-Issue costs per class (true shader cycles per wave-instruction per SIMD; tools/ubench/valu_rates.hip measures each
-instruction's time AND the clock it ran at, profiles/r04_valu_issue_rates.txt):
-    fast   2.4   v_fma/mul/add/sub_f32 (also with clamp / |x| / -x modifiers), v_mov, 2-operand integer add/sub/shift/and/or
+Issue costs per class (true shader cycles per wave-instruction per SIMD at 8 waves per SIMD; tools/ubench/valu_rates.hip
+measures each instruction's time AND, with s_memtime / s_memrealtime inside the kernel, the clock it ran at,
+profiles/r04_valu_issue_rates.txt):
+    fast   2.35  v_fma/mul/add/sub_f32 (also with clamp / |x| / -x modifiers), v_mov, 2-operand integer add/sub/shift/and/or
     slow   4.15  v_min/max/med3, v_cvt_*, v_cmp, v_cndmask, 3-operand integer ops, v_mul_lo/hi, every DPP-modified op, v_fma_mix ...
     pk     4.15  v_pk_* (f32 and f16)
-    trans  8.1   v_rcp/rsq/sqrt/exp/log/sin/cos
+    trans  8.15  v_rcp/rsq/sqrt/exp/log/sin/cos
+MODEL ERROR.  The costs are those of homogeneous streams and the model adds them up.  Mixed streams measured in the same file
+deviate: fast and slow ops alternating cost 0.69-0.81 of the sum (they overlap: 2.26-2.64 instead of 3.25 cycles per
+instruction), fast + packed 1.18 (3.84 instead of 3.25), fast + transcendental 1.17, slow + packed and slow / packed +
+transcendental 1.00, and a stream shaped like EASU's pair block (3 packed, 4 fast, 1 slow per 8) 1.06.  So a kernel's issue
+cycles carry about -15 % ... +6 % of model error on top of the LP interval: an issue_frac of 0.9-1.1 reads "the VALU issues
+back to back", 0.7 reads "it does not" -- which is the distinction the figure is for.
 """
 import argparse
 import json
@@ -42,7 +49,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
-COST = {"fast": 2.4, "slow": 4.15, "pk": 4.15, "trans": 8.1}
+COST = {"fast": 2.35, "slow": 4.15, "pk": 4.15, "trans": 8.15}
 VALU_CLASSES = ("fast", "slow", "pk", "trans")
 COUNT_KEYS = VALU_CLASSES + ("salu", "lds", "vmem_rd", "vmem_wr", "smem", "branch", "other")
 

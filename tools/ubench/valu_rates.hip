@@ -118,6 +118,32 @@ KERNEL(k_mix_1t_7f, MIX_1T_7F)
 KERNEL(k_mix_2t_6f, MIX_2T_6F)
 KERNEL(k_mix_1t_7s, MIX_1T_7S)
 KERNEL(k_mix_4s_4f, MIX_4S_4F)
+
+// The full pair matrix: strict alternation X Y X Y ... of two classes (4 + 4 per BODY), scalar and packed registers in one kernel.
+// tools/isa_costs.py prices an instruction by its class AND the class of the VALU instruction in front of it from these.
+#define P1(R, Q) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(R) : "v"(Q));
+#define MKERNEL(NAME, BODY)                                                                        \
+    __global__ __launch_bounds__(256) void NAME(float *out, int iters, float seed)                 \
+    {                                                                                             \
+        float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
+        float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * .5f, b3 = a3 * .5f, b4 = a4 * .5f, b5 = a5 * .5f, b6 = a6 * .5f, b7 = a7 * .5f;        \
+        float2v p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};                        \
+        float2v q0 = p0 * .5f, q1 = p1 * .5f, q2 = p2 * .5f, q3 = p3 * .5f;                        \
+        OVR_T0 for (int i = 0; i < iters; ++i) { REP8(BODY) }                                      \
+        float2v r = p0 + p1 + p2 + p3 + q0 + q1 + q2 + q3;                                         \
+        OVR_T1 out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y + a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7; \
+    }
+MKERNEL(k_alt_fs, F1(a0, b0) S1(a1, b1) F1(a2, b2) S1(a3, b3) F1(a4, b4) S1(a5, b5) F1(a6, b6) S1(a7, b7))
+MKERNEL(k_alt_fp, F1(a0, b0) P1(p0, q0) F1(a2, b2) P1(p1, q1) F1(a4, b4) P1(p2, q2) F1(a6, b6) P1(p3, q3))
+MKERNEL(k_alt_ft, F1(a0, b0) T1(a1, b1) F1(a2, b2) T1(a3, b3) F1(a4, b4) T1(a5, b5) F1(a6, b6) T1(a7, b7))
+MKERNEL(k_alt_sp, S1(a0, b0) P1(p0, q0) S1(a2, b2) P1(p1, q1) S1(a4, b4) P1(p2, q2) S1(a6, b6) P1(p3, q3))
+MKERNEL(k_alt_st, S1(a0, b0) T1(a1, b1) S1(a2, b2) T1(a3, b3) S1(a4, b4) T1(a5, b5) S1(a6, b6) T1(a7, b7))
+MKERNEL(k_alt_pt, P1(p0, q0) T1(a1, b1) P1(p1, q1) T1(a3, b3) P1(p2, q2) T1(a5, b5) P1(p3, q3) T1(a7, b7))
+// runs of two: X X Y Y X X Y Y (does the pairing depend on adjacency only?)
+MKERNEL(k_run2_fs, F1(a0, b0) F1(a1, b1) S1(a2, b2) S1(a3, b3) F1(a4, b4) F1(a5, b5) S1(a6, b6) S1(a7, b7))
+MKERNEL(k_run2_fp, F1(a0, b0) F1(a1, b1) P1(p0, q0) P1(p1, q1) F1(a4, b4) F1(a5, b5) P1(p2, q2) P1(p3, q3))
+// the mix of the EASU pair block: 3 packed, 3 fast, 1 slow per 7 (+1 fast)
+MKERNEL(k_easu_like, P1(p0, q0) F1(a0, b0) P1(p1, q1) F1(a1, b1) S1(a2, b2) P1(p2, q2) F1(a3, b3) F1(a4, b4))
 KERNEL(k_rcp_f16, V8_1("v_rcp_f16"))
 KERNEL(k_sub_u32, V8_2("v_sub_u32"))
 KERNEL(k_lshrrev, V8_2("v_lshrrev_b32"))
@@ -335,7 +361,10 @@ int main()
         {"v_cvt_f32_f16", k_cvt_f32_f16, 64}, {"v_cvt_f16_f32", k_cvt_f16_f32, 64}, {"v_cvt_pkrtz_f16_f32", k_cvt_pkrtz, 64},
         {"v_cvt_f32_ubyte0", k_cvt_f32_ubyte0, 64},
         {"v_rcp_f32", k_rcp_f32, 64}, {"mix 1 rcp + 7 fma (per 8)", k_mix_1t_7f, 64}, {"mix 2 rcp + 6 fma (per 8)", k_mix_2t_6f, 64},
-        {"mix 1 rcp + 7 min3 (per 8)", k_mix_1t_7s, 64}, {"mix 4 min3 + 4 fma (per 8)", k_mix_4s_4f, 64}, {"v_rcp_f16", k_rcp_f16, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_lshrrev_b32", k_lshrrev, 64},
+        {"mix 1 rcp + 7 min3 (per 8)", k_mix_1t_7s, 64}, {"mix 4 min3 + 4 fma (per 8)", k_mix_4s_4f, 64},
+        {"alt F S  (fma, min3)", k_alt_fs, 64}, {"alt F P  (fma, pk_fma)", k_alt_fp, 64}, {"alt F T  (fma, rcp)", k_alt_ft, 64},
+        {"alt S P  (min3, pk_fma)", k_alt_sp, 64}, {"alt S T  (min3, rcp)", k_alt_st, 64}, {"alt P T  (pk_fma, rcp)", k_alt_pt, 64},
+        {"runs FFSS", k_run2_fs, 64}, {"runs FFPP", k_run2_fp, 64}, {"easu-like 3P 4F 1S", k_easu_like, 64}, {"v_rcp_f16", k_rcp_f16, 64}, {"v_sub_u32", k_sub_u32, 64}, {"v_lshrrev_b32", k_lshrrev, 64},
         {"v_min_u32", k_min_u32, 64}, {"v_max_i32", k_max_i32, 64}, {"v_min3_u32", k_min3_u32, 64}, {"v_max_f32", k_max_f32, 64}, {"v_max3_f32", k_max3_f32, 64},
         {"v_and_b32", k_and_b32, 64}, {"v_or_b32", k_or_b32, 64}, {"v_lshl_or_b32", k_lshl_or_b32, 64}, {"v_lshl_add_u32", k_lshl_add_u32, 64},
         {"v_add3_u32", k_add3_u32, 64}, {"v_perm_b32", k_perm_b32, 64}, {"v_bfe_u32", k_bfe_u32, 64}, {"v_cvt_pk_u8_f32", k_cvt_pk_u8_f32, 64},
