@@ -170,14 +170,18 @@ static hipError_t fused_go3(bool strict, const FusedArgs &a, dim3 grid, size_t l
     }
     return hipGetLastError();
 }
+// The intermediate has the submission's format (R8G8B8A8 -> UNORM8, RGBA16F -> half: PostProcessor::IntermediateFormat, which
+// mirrors DetermineOutputFormat, PostProcessor.cpp:63-74) or, with quantize_intermediate = 0, stays in float: those are the only
+// (input, intermediate) pairs a ctx ever asks for, so only they are instantiated (12 of the 27 format triples of the fused and
+// outside-tile kernels were dead weight in the library until round 4).
+template <int I, int M> constexpr bool mid_reachable() { return M == I || M == FMT_RGBA32F; }
+
 template <int I, int O>
 static hipError_t fused_go(int mid_fmt, bool strict, const FusedArgs &a, dim3 grid, size_t lds, hipStream_t s)
 {
-    switch (mid_fmt) {
-    case FMT_RGBA8: return fused_go3<I, FMT_RGBA8, O>(strict, a, grid, lds, s);
-    case FMT_RGBA16F: return fused_go3<I, FMT_RGBA16F, O>(strict, a, grid, lds, s);
-    default: return fused_go3<I, FMT_RGBA32F, O>(strict, a, grid, lds, s);
-    }
+    if (mid_fmt == (int)I) return fused_go3<I, I, O>(strict, a, grid, lds, s);
+    if (mid_fmt == FMT_RGBA32F) return fused_go3<I, FMT_RGBA32F, O>(strict, a, grid, lds, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
@@ -199,12 +203,10 @@ hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const Fu
 template <int I, int O>
 static hipError_t easu_outside_go(int mid_fmt, const EasuArgs &a, dim3 grid, hipStream_t s)
 {
-    switch (mid_fmt) {
-    case FMT_RGBA8: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, FMT_RGBA8>), grid, dim3(kThreads), 0, s, a); break;
-    case FMT_RGBA16F: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, FMT_RGBA16F>), grid, dim3(kThreads), 0, s, a); break;
-    case FMT_RGBA32F: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, FMT_RGBA32F>), grid, dim3(kThreads), 0, s, a); break;
-    default: hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, -1>), grid, dim3(kThreads), 0, s, a); break;
-    }
+    if (mid_fmt < 0) hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, -1>), grid, dim3(kThreads), 0, s, a);
+    else if (mid_fmt == FMT_RGBA32F) hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, FMT_RGBA32F>), grid, dim3(kThreads), 0, s, a);
+    else if (mid_fmt == (int)I && I != FMT_RGB10A2) hipLaunchKernelGGL((ovrfsr_fast::easu_outside_kernel<I, O, (I == FMT_RGB10A2 ? -1 : I)>), grid, dim3(kThreads), 0, s, a);
+    else return hipErrorInvalidValue; // not an (input, intermediate) pair a ctx produces (see mid_reachable)
     return hipGetLastError();
 }
 
@@ -228,10 +230,10 @@ static hipError_t outside_staged_go(int mid_fmt, const OutsideArgs &a, dim3 grid
     } else if constexpr (TH == 24) { // NIS DirectCopy
         hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<24, I, O, FMT_RGBA32F>), grid, dim3(8 * 24), lds, s, a);
     } else {
-        switch (mid_fmt) {
+        switch (mid_fmt) { // RGBA8 sources: a UNORM8 or a float intermediate, or the EASU pass alone
         case FMT_RGBA8: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA8>), grid, dim3(256), lds, s, a); break;
-        case FMT_RGBA16F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA16F>), grid, dim3(256), lds, s, a); break;
         case FMT_RGBA32F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA32F>), grid, dim3(256), lds, s, a); break;
+        case FMT_RGBA16F: return hipErrorInvalidValue;
         default: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, -1>), grid, dim3(256), lds, s, a); break;
         }
     }
