@@ -70,7 +70,7 @@ struct EasuArgs {
     uint32_t outsideCols, outsideRows; // largest bilinear footprint of a 32x32 tile (outside_staged_kernel's LDS plane)
     float rcpOutW, rcpOutH;   // RN(1/outW), RN(1/outH): o/out as mul + 2 fma (Markstein), see div_exact
     uint32_t rcpExact;        // host verified that form against IEEE division for every o < outW (outH); else 0
-    float tieHalfMin;         // near-tie guard of RGBA16F stores: values below it are not guarded (see near_tie_half); +inf = off
+    float tieHalfMin;         // near-tie guard of RGBA16F stores: values below it are not guarded (see half_tie_code); +inf = off
     uint32_t ringStrips;      // mask-sorted form: a listed tile with no group inside the radius is a RING tile whose output only
                               // feeds the RCAS taps of inside neighbours -- write just the edge pixels those taps read
 };

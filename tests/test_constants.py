@@ -155,9 +155,10 @@ def test_unorm8_decode_two_op_form_is_correctly_rounded():
 
 
 def test_near_tie_band_formulas():
-    """The near-tie guard's band tests (fsr_device.inc: near_tie_byte, near_tie_half), restated in numpy float32 arithmetic
-    and checked against the plain definition: a byte-domain value v is flagged iff frac(v) lies within 2^-9 of 0.5; a unit-domain
-    value x >= xmin is flagged iff it lies within 2^-17 of the midpoint of two neighbouring half values.  (The device functions
+    """The near-tie guard's band tests (fsr_device.inc: near_tie_byte, half_tie_code), restated in numpy arithmetic
+    and checked against the plain definition: a byte-domain value v is flagged iff frac(v) lies within 2^-9 of 0.5; a value
+    x >= xmin about to be stored as half is flagged iff it lies within 2^-6 of a half spacing of the midpoint of two neighbouring
+    half values (2^-17 in [0.5, 1), growing with the binade).  (The device functions
     are these expressions; the GPU tests prove their effect -- n_diff == 0 -- this pins the band they implement.)"""
     K = 9
     rng = np.random.default_rng(5)
@@ -171,20 +172,29 @@ def test_near_tie_band_formulas():
     assert not flagged[dist > 2.0 ** -K + ulp].any()
     assert 0.9 * 2.0 ** (1 - K) < flagged[:200000].mean() < 1.1 * 2.0 ** (1 - K)   # 2^(1-K) of uniformly distributed values
 
-    band = np.float32(2.0 ** -17)
-    x = np.concatenate([rng.uniform(0.02, 1.9, 200000), np.float32(0.5) - rng.uniform(0, 3e-4, 2000), np.float32(1.0) - rng.uniform(0, 6e-4, 2000)]).astype(np.float32)
-    back = x.astype(np.float16).astype(np.float32)
-    half_step = ((x.view(np.uint32) & np.uint32(0x7f800000)) - np.uint32(11 << 23)).view(np.float32)
-    for xmin in (np.float32(0.25), np.float32(0.5)):
-        flagged = ((np.abs(x - back) + band).astype(np.float32) > half_step) & (x >= xmin)
-        # definition: distance of x to the nearest midpoint between consecutive half values
-        lo = np.minimum(back, x.astype(np.float64))
-        h16 = back.astype(np.float16)
-        up = np.nextafter(h16, np.float16(np.inf)).astype(np.float64)
-        dn = np.nextafter(h16, np.float16(-np.inf)).astype(np.float64)
-        mid = np.where(x.astype(np.float64) >= back, (back + up) / 2, (back + dn) / 2)
-        d = np.abs(x.astype(np.float64) - mid)
+    # half stores (round 4: half_tie_code, fsr_device.inc): the low 13 bits of the fp32 pattern are x's position inside its half
+    # spacing; flagged iff within 2^-6 of a SPACING of the boundary (midpoint of two neighbouring half values) and x >= xmin.
+    # The band is relative: 2^-17 in [0.5, 1), 2^-16 in [1, 2), 2^-12 in [16, 32) ...
+    KH = 6
+    W = np.uint32(1 << (13 - KH))
+    M = np.uint32(0x1fff & ~(2 * int(W) - 1))
+    x = np.concatenate([rng.uniform(0.02, 1.9, 200000), rng.uniform(2.0, 60.0, 50000), np.float32(0.5) - rng.uniform(0, 3e-4, 2000),
+                        np.float32(1.0) - rng.uniform(0, 6e-4, 2000), -rng.uniform(0.3, 2.0, 1000)]).astype(np.float32)
+    bits = x.view(np.uint32)
+    h16 = x.astype(np.float16)
+    back = h16.astype(np.float64)
+    up = np.nextafter(h16, np.float16(np.inf)).astype(np.float64)
+    dn = np.nextafter(h16, np.float16(-np.inf)).astype(np.float64)
+    x64 = x.astype(np.float64)
+    mid = np.where(x64 >= back, (back + up) / 2, (back + dn) / 2)
+    # spacing of x's OWN binade (a value just below a power of two rounds up into the next one; the code follows x)
+    spacing = 2.0 ** (np.floor(np.log2(np.abs(x64))) - 10)
+    d = np.abs(x64 - mid) / spacing
+    for xmin in (np.float32(0.25), np.float32(0.5), np.float32(np.inf)):
+        xb = np.float32(xmin).view(np.uint32)
+        code = (((bits + W) & M) ^ np.uint32(0x1000)) | (((bits - xb) | bits) & np.uint32(0x80000000))
+        flagged = code == 0
         sel = x >= xmin
-        assert flagged[sel & (d < float(band) * 0.999)].all()
-        assert not flagged[sel & (d > float(band) * 1.001 + 1e-9)].any()
-        assert not flagged[~sel].any()
+        assert flagged[sel & (d < 2.0 ** -KH * 0.99)].all()
+        assert not flagged[sel & (d > 2.0 ** -KH * 1.01 + 2.0 ** -12)].any()   # the fixed-point position has 13 bits
+        assert not flagged[~sel].any()                                          # below xmin, negative, and everything when xmin = +inf

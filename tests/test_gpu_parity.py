@@ -536,7 +536,7 @@ def test_fused_half_float_and_full_size(gpu):
     two = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5, fused=0)
     one = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5, fused=1)
     assert np.array_equal(one.view(np.uint16), two.view(np.uint16))
-    # product build: both forms guard the half intermediate's near-ties (near_tie_half), so what is left between them is
+    # product build: both forms guard the half intermediate's near-ties (near_tie_half3), so what is left between them is
     # the final half rounding of RCAS's output
     two = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5, fused=0).astype(np.float32)
     one = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5, fused=1).astype(np.float32)

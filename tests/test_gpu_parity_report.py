@@ -152,7 +152,7 @@ def test_c5_masked_half(gpu, content, seed):
     assert r["n_diff"] == 0
     r = _rec("C5", "product", tag, "half", run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5), want)
     # the half intermediate's near-ties are re-resolved in the reference's operator order wherever a flipped half-ulp could
-    # exceed the tolerance behind RCAS's gain (near_tie_half): north_star's bound holds on every value
+    # exceed the tolerance behind RCAS's gain (near_tie_half3): north_star's bound holds on every value
     assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
 
 
