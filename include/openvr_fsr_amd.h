@@ -67,8 +67,9 @@ typedef enum ovrfsr_format {
  * (`//#define A_HALF`, src/fsr/fsr_easu.hlsl:3).
  *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp): the product build.  Its quantised EASU stores
  *                (the UNORM8 / half intermediate, an EASU-only UNORM8 output) are nevertheless the STRICT build's -- EMPIRICALLY bit for
- *                bit: pixels whose result lies within 2^-9 byte (for half stores: 2^-6 of a half spacing, values in
- *                [xmin, 2) with xmin = 0.25 / 0.5 derived from the sharpness) of a rounding boundary are re-resolved in the
+ *                bit: pixels whose result lies within 2^-9 byte (for half stores: within 2^-6 of a half spacing -- a band that
+ *                follows the value's binade --, for values >= xmin = 0.25 / 0.5 derived from the sharpness: a flipped half-ulp below
+ *                xmin stays under 1e-3 behind RCAS's largest gain) of a rounding boundary are re-resolved in the
  *                reference's operator order (near-tie guard).  The band is 3x the largest re-association error
  *                MEASURED (6.5e-4 byte over 1e8 values incl. adversarial content, tools/debug/easu_err.py is the audit:
  *                it re-resolves every pixel with the strict build and reports any value outside the band); it is not a
