@@ -122,15 +122,24 @@ static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t
     }                                                                                                    \
     return hipErrorInvalidValue;
 
-// LDS of the fused kernel: EASU planes + 34x34 float4 intermediate
-size_t fused_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH)
+// LDS of the fused kernel: EASU planes + 34x34 intermediate.  Product build with OVRFSR_FUSED_NARROW: the colour plane of
+// RGBA8 / RGBA16F input and a UNORM8 / half intermediate are planes of four halves (8 bytes per cell; fused_kernel).
+size_t fused_lds_bytes(int prec, int in_fmt, int mid_fmt, int cellsW, int cellsH)
 {
     size_t e = easu_lds_bytes(prec, in_fmt, cellsW, cellsH);
     e = (e + 15) & ~(size_t)15;
-    // product build: the luma plane doubles as the near-tie list region (fused_kernel) and is at least that large
-    if (prec != PREC_FP32_STRICT && easu_fast_pitch(cellsW) != 0 && (size_t)easu_fast_pitch(cellsW) * cellsH * 4 < kFusedTieListBytes)
-        e += kFusedTieListBytes;
-    return e + (size_t)(kTileW + 2) * (kTileH + 2) * 16;
+    size_t midCell = 16;
+    if (prec != PREC_FP32_STRICT && easu_fast_pitch(cellsW) != 0) {
+        const size_t ncell = (size_t)easu_fast_pitch(cellsW) * cellsH;
+        // the luma plane doubles as the near-tie list region (fused_kernel) and is at least that large
+        if (ncell * 4 < kFusedTieListBytes) e += kFusedTieListBytes;
+#if OVRFSR_FUSED_NARROW
+        if (in_fmt == FMT_RGBA8 || in_fmt == FMT_RGBA16F) e -= ncell * 8;
+        if (mid_fmt == FMT_RGBA8 || mid_fmt == FMT_RGBA16F) midCell = 8;
+#endif
+    }
+    (void)mid_fmt;
+    return e + (size_t)(kTileW + 2) * (kTileH + 2) * midCell;
 }
 
 template <int I, int M, int O>
@@ -195,7 +204,7 @@ hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const Fu
     // OVRFSR_FUSED_LDS_PAD=<bytes> (diagnostic): extra dynamic LDS nobody touches -> fewer workgroups per CU; measures how the kernel's
     // throughput follows its occupancy (profiles/r04_fused_variants.txt) before anyone rebuilds its planes to gain a workgroup
     static const size_t pad = [] { const char *e = std::getenv("OVRFSR_FUSED_LDS_PAD"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 0); }();
-    size_t lds = fused_lds_bytes(prec, in_fmt, a.cellsW, a.cellsH) + pad;
+    size_t lds = fused_lds_bytes(prec, in_fmt, mid_fmt, a.cellsW, a.cellsH) + pad;
     if (lds > kFusedLdsMax) lds = kFusedLdsMax;
     OVRFSR_DISPATCH_FMT3(fused_go, mid_fmt, strict, a, grid, lds, s)
 }

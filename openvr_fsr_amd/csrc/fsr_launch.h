@@ -8,7 +8,7 @@ namespace ovrfsr {
 size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH);
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles = 0);
 hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s);
-size_t fused_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH);
+size_t fused_lds_bytes(int prec, int in_fmt, int mid_fmt, int cellsW, int cellsH);
 hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles = 0);
 hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles = 0);
 int nis_pitch(int cellsW);

@@ -310,7 +310,7 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
     const bool tenBit = in.format == OVRFSR_FORMAT_RGB10A2_UNORM; // two-kernel pipeline only (header)
     if (tenBit && cfg_.fused == 1) return Fail(OVRFSR_ERR_UNSUPPORTED, "the fused kernel is not built for RGB10A2 images");
     const bool autoFused = !tenBit && cfg_.fused == -1 && tileListDev_ != nullptr && fusedCellsW_ <= 40 &&
-                           fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) <= kFusedLdsMax;
+                           fused_lds_bytes(cfg_.precision, (int)in.format, (int)IntermediateFormat(), fusedCellsW_, fusedCellsH_) <= kFusedLdsMax;
     // auto on a masked product-build EASU+RCAS pipeline: the two-pass kernels on the tiles touching the radius, tiles
     // outside written in final form (ApplySorted); cfg.fused = 1 keeps the single fused kernel on those tiles
     // Measured: with 4-byte pixels the sorted two-pass form wins (C2 shape, radius 0.5: +13 %); with 8/16-byte
@@ -320,7 +320,7 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
                  in.format == OVRFSR_FORMAT_RGBA8_UNORM && IntermediateFormat() == OVRFSR_FORMAT_RGBA8_UNORM;
     if ((cfg_.fused == 1 || (autoFused && !useSorted_)) && doUpscale_ && doSharpen_ && !cfg_.use_nis) {
         const bool pitchOk = cfg_.precision == OVRFSR_PRECISION_FP32_STRICT || fusedCellsW_ <= 40;
-        if (!pitchOk || fused_lds_bytes(cfg_.precision, (int)in.format, fusedCellsW_, fusedCellsH_) > kFusedLdsMax)
+        if (!pitchOk || fused_lds_bytes(cfg_.precision, (int)in.format, (int)IntermediateFormat(), fusedCellsW_, fusedCellsH_) > kFusedLdsMax)
             return Fail(OVRFSR_ERR_UNSUPPORTED, "fused kernel: tile footprint does not fit LDS at this scale");
         useFused_ = true;
     }
