@@ -70,10 +70,12 @@ typedef enum ovrfsr_format {
  *                bit: pixels whose result lies within 2^-9 byte (for half stores: within 2^-6 of a half spacing -- a band that
  *                follows the value's binade --, for values >= xmin = 0.25 / 0.5 derived from the sharpness: a flipped half-ulp below
  *                xmin stays under 1e-3 behind RCAS's largest gain) of a rounding boundary are re-resolved in the
- *                reference's operator order (near-tie guard).  The band is 3x the largest re-association error
- *                MEASURED (6.5e-4 byte over 1e8 values incl. adversarial content, tools/debug/easu_err.py is the audit:
- *                it re-resolves every pixel with the strict build and reports any value outside the band); it is not a
- *                derived bound, and HDR half inputs whose taps span many binades are outside what was measured.  Float
+ *                reference's operator order (near-tie guard).  The band is 6.7x the largest distance between
+ *                the two evaluations that a DIRECTED search could produce (2.9e-4 byte: tools/debug/easu_err_search.py evolves
+ *                texel patches to maximise it; the filter's one ill-conditioned step, the direction blend, is evaluated in
+ *                the reference's order for that reason -- the contracted form reached three bands) and 3x the largest found
+ *                on images (tools/debug/easu_err.py); it is not a derived bound, and HDR half inputs whose taps span many
+ *                binades are outside what was searched.  Float
  *                outputs differ by <= 3e-6, UNORM8 pipeline outputs by <= 1 LSB
  *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
  *                to the CPU oracle; a validation build, not a fast one

@@ -12,8 +12,9 @@ their own patch, and the patch with the largest distance becomes the next champi
 
 NIS=1 in the environment searches NVScaler (use_nis, sharpness 0.9; 12x12 patches for its 6x6 support + interpolated edge map) instead;
 there is no guard on that path: its contract is <= 1 LSB, and the distance shows how much of it re-association may use.
+PIPE=1 searches the EASU -> RCAS pipeline's float output (10x10 patches): with the intermediate bit-identical, RCAS's own distance.
 
-Usage: [NIS=1] python tools/debug/easu_err_search.py [generations=400] [seed=1] [scales=0,1,2,3]      (GPU; OVRFSR_LIB selects the library)
+Usage: [NIS=1 | PIPE=1] python tools/debug/easu_err_search.py [generations=400] [seed=1] [scales=0,1,2,3]      (GPU; OVRFSR_LIB selects the library)
 """
 import os
 import sys
@@ -25,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 STRICT, FP32 = 2, 0
-NIS = os.environ.get("NIS", "0") == "1"
+NIS = "pipe" if os.environ.get("PIPE", "0") == "1" else os.environ.get("NIS", "0") == "1"
 P = 8   # patch edge in texels (set by search(): 8 for EASU, 12 for NVScaler; 30 / 20 patches per image edge -> 240 x 240 texels,
         # divisible by 3 and 10: exact output sizes at every scale of SCALES)
 BAND = 2.0 ** -9
@@ -92,8 +93,12 @@ SCALES = (("scale 3/4 (C2)", 4, 3), ("scale 0.77 (C4 shape)", 13, 10), ("scale 1
 def search(scale_index, gens, seed, nis=False, verbose=True):
     """(1 + lambda) evolution at SCALES[scale_index]; returns (worst distance in bytes, champion patch)."""
     from tests.util import run_gpu
-    kw = dict(use_nis=1, sharpness=0.9) if nis else dict(stage_mask=1)
-    p, g_, lo, hi = (12, 20, 4, 7) if nis else (8, 30, 2, 4)
+    if nis == "pipe":   # EASU -> RCAS, float output (the intermediate keeps its format rounding): RCAS's own re-association distance
+        kw, (p, g_, lo, hi) = dict(sharpness=0.9), (10, 24, 3, 6)
+    elif nis:
+        kw, (p, g_, lo, hi) = dict(use_nis=1, sharpness=0.9), (12, 20, 4, 7)
+    else:
+        kw, (p, g_, lo, hi) = dict(stage_mask=1), (8, 30, 2, 4)
     global P
     P = p   # fresh() / mutate() read the patch edge
     name, num, den = SCALES[scale_index]
@@ -147,7 +152,7 @@ def main():
     gens = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     pick = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(SCALES))
-    print("lib:", os.environ.get("OVRFSR_LIB", "(default)"), "NVScaler" if NIS else "EASU", " %d generations, seed %d, band 2^-9 = %.3e byte" % (gens, seed, BAND))
+    print("lib:", os.environ.get("OVRFSR_LIB", "(default)"), "EASU+RCAS" if NIS == "pipe" else "NVScaler" if NIS else "EASU", " %d generations, seed %d, band 2^-9 = %.3e byte" % (gens, seed, BAND))
     for i in pick:
         search(i, gens, seed, nis=NIS)
 
