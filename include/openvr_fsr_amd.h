@@ -74,8 +74,9 @@ typedef enum ovrfsr_format {
  *                the two evaluations that a DIRECTED search could produce (2.9e-4 byte: tools/debug/easu_err_search.py evolves
  *                texel patches to maximise it; the filter's one ill-conditioned step, the direction blend, is evaluated in
  *                the reference's order for that reason -- the contracted form reached three bands) and 3x the largest found
- *                on images (tools/debug/easu_err.py); it is not a derived bound, and HDR half inputs whose taps span many
- *                binades are outside what was searched.  Float
+ *                on images (tools/debug/easu_err.py); it is not a derived bound.  The half band holds with the same margin for
+ *                unit-range RGBA16F images (0.2 of the band under the search); for HDR texels (taps 40x the output value: 2.9
+ *                bands) the error follows the largest tap, the band the output: such a half store may be one half-ulp off.  Float
  *                outputs differ by <= 3e-6, UNORM8 pipeline outputs by <= 1 LSB
  *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
  *                to the CPU oracle; a validation build, not a fast one

@@ -12,6 +12,7 @@ their own patch, and the patch with the largest distance becomes the next champi
 
 NIS=1 in the environment searches NVScaler (use_nis, sharpness 0.9; 12x12 patches for its 6x6 support + interpolated edge map) instead;
 there is no guard on that path: its contract is <= 1 LSB, and the distance shows how much of it re-association may use.
+HALF=1 [HSCALE=s] searches EASU on RGBA16F texels half(b/255*s) against the HALF guard's relative band (outputs >= 0.5).
 PIPE=1 searches the EASU -> RCAS pipeline's float output (10x10 patches): with the intermediate bit-identical, RCAS's own distance.
 
 Usage: [NIS=1 | PIPE=1] python tools/debug/easu_err_search.py [generations=400] [seed=1] [scales=0,1,2,3]      (GPU; OVRFSR_LIB selects the library)
@@ -26,7 +27,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 STRICT, FP32 = 2, 0
-NIS = "pipe" if os.environ.get("PIPE", "0") == "1" else os.environ.get("NIS", "0") == "1"
+NIS = "pipe" if os.environ.get("PIPE", "0") == "1" else "half" if os.environ.get("HALF", "0") == "1" else os.environ.get("NIS", "0") == "1"
+HSCALE = float(os.environ.get("HSCALE", "1.0"))   # HALF=1: texel = half(b / 255 * HSCALE)
 P = 8   # patch edge in texels (set by search(): 8 for EASU, 12 for NVScaler; 30 / 20 patches per image edge -> 240 x 240 texels,
         # divisible by 3 and 10: exact output sizes at every scale of SCALES)
 BAND = 2.0 ** -9
@@ -93,7 +95,10 @@ SCALES = (("scale 3/4 (C2)", 4, 3), ("scale 0.77 (C4 shape)", 13, 10), ("scale 1
 def search(scale_index, gens, seed, nis=False, verbose=True):
     """(1 + lambda) evolution at SCALES[scale_index]; returns (worst distance in bytes, champion patch)."""
     from tests.util import run_gpu
-    if nis == "pipe":   # EASU -> RCAS, float output (the intermediate keeps its format rounding): RCAS's own re-association distance
+    half = nis == "half"
+    if half:            # EASU of RGBA16F texels, float output; distance in units of the HALF guard's band at the output value (>= 0.5 only)
+        kw, (p, g_, lo, hi) = dict(stage_mask=1), (8, 30, 2, 4)
+    elif nis == "pipe":   # EASU -> RCAS, float output (the intermediate keeps its format rounding): RCAS's own re-association distance
         kw, (p, g_, lo, hi) = dict(sharpness=0.9), (10, 24, 3, 6)
     elif nis:
         kw, (p, g_, lo, hi) = dict(use_nis=1, sharpness=0.9), (12, 20, 4, 7)
@@ -123,9 +128,15 @@ def search(scale_index, gens, seed, nis=False, verbose=True):
         img[..., 3] = 255
         arr = np.stack(patches).reshape(g_, g_, p, p, 3)
         img[..., :3] = arr.transpose(0, 2, 1, 3, 4).reshape(ih, iw, 3)
-        fs = run_gpu(img, ow, oh, np.float32, precision=STRICT, **kw)
-        fp = run_gpu(img, ow, oh, np.float32, precision=FP32, **kw)
-        d = np.abs(fp[..., :3].astype(np.float64) - fs[..., :3].astype(np.float64)).max(axis=2) * 255.0
+        src = (img.astype(np.float32) * np.float32(HSCALE / 255.0)).astype(np.float16) if half else img
+        fs = run_gpu(src, ow, oh, np.float32, precision=STRICT, **kw)
+        fp = run_gpu(src, ow, oh, np.float32, precision=FP32, **kw)
+        if half:
+            a, b = fp[..., :3].astype(np.float64), fs[..., :3].astype(np.float64)
+            band = 2.0 ** (np.floor(np.log2(np.maximum(b, 2.0 ** -14))) - 10 - 6)   # 2^-6 of the half spacing of the reference value
+            d = (np.where(b >= 0.5, np.abs(a - b) / band, 0.0)).max(axis=2) * BAND  # in "bands", scaled so that the printout's ratio is right
+        else:
+            d = np.abs(fp[..., :3].astype(np.float64) - fs[..., :3].astype(np.float64)).max(axis=2) * 255.0
         d = np.where(ok, d, 0.0)
         per = np.zeros(g_ * g_)
         np.maximum.at(per, pid.ravel(), d.ravel())
@@ -134,6 +145,9 @@ def search(scale_index, gens, seed, nis=False, verbose=True):
             best, champ = float(per[j]), patches[j]
         if verbose and (g in (0, 9, 49, 99, 199) or (g + 1) % 500 == 0 or g == gens - 1):
             print("  %-22s generation %4d: worst distance found %.3e byte (%.2f of the band), %.0f s" % (name, g + 1, best, best / BAND, time.time() - t0), flush=True)
+    if verbose and half:
+        print("  %-22s (HALF: distances are in units of the half guard's band at the output value, x 2^-9 for the printout; outputs >= 0.5 only)" % name)
+        return best, champ
     if verbose:
         print("  %-22s champion patch (R plane): %s" % (name, champ[..., 0].tolist()))
         # how the champion fares in the UNORM8 output (the guard's job): both builds, bytes that differ
@@ -152,7 +166,7 @@ def main():
     gens = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     pick = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(SCALES))
-    print("lib:", os.environ.get("OVRFSR_LIB", "(default)"), "EASU+RCAS" if NIS == "pipe" else "NVScaler" if NIS else "EASU", " %d generations, seed %d, band 2^-9 = %.3e byte" % (gens, seed, BAND))
+    print("lib:", os.environ.get("OVRFSR_LIB", "(default)"), "EASU+RCAS" if NIS == "pipe" else "EASU of RGBA16F texels (x%g)" % HSCALE if NIS == "half" else "NVScaler" if NIS else "EASU", " %d generations, seed %d, band 2^-9 = %.3e byte" % (gens, seed, BAND))
     for i in pick:
         search(i, gens, seed, nis=NIS)
 
