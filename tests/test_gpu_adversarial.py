@@ -37,3 +37,46 @@ def test_nvscaler_search_well_inside_one_lsb():
     m = _tool()
     best, _ = m.search(1, 60, 2, nis=True, verbose=False)
     assert best < 5e-3, best
+
+
+def _patch_image(m, seed, mutated):
+    """240x240 RGBA8 image of 30x30 patches of the search's content families (random, two-level edges, extremes, ramps, flat with
+    outliers, checkerboards); mutated: two thirds of them are mutants of one patch (constant rows / columns, copied neighbours ...)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    m.P = 8
+    base = m.fresh(rng)
+    patches = []
+    for i in range(900):
+        p = m.fresh(rng) if (not mutated or i % 3 == 0) else m.mutate(rng, m.mutate(rng, base))
+        patches.append(p)
+    img = np.empty((240, 240, 4), np.uint8)
+    img[..., 3] = 255
+    img[..., :3] = np.stack(patches).reshape(30, 30, 8, 8, 3).transpose(0, 2, 1, 3, 4).reshape(240, 240, 3)
+    return img
+
+
+@pytest.mark.parametrize("ow,seed,mutated", [(320, 11, False), (480, 12, True), (312, 13, True)])
+def test_adversarial_content_against_the_oracle(ow, seed, mutated):
+    """The search's content (cancelling gradients, extremes next to flats) through the ORACLE, not only strict vs product: the strict
+    build is bit-identical on it, the product build's UNORM8 EASU output is identical (near-tie guard) and its pipeline within 1 LSB"""
+    import numpy as np
+    from oracle import oracle as O
+    from tests.util import run_gpu, lsb_stats
+    m = _tool()
+    img8 = _patch_image(m, seed, mutated)
+    con = O.easu_con(240, 240, ow, ow)
+    centre, rad = O.mask_constants(ow, ow, 2.0, (0.5, 0.5, 0.5, 0.5), True, 0)
+    want = O.easu(O.unorm8_to_float(img8), ow, ow, con, centre, rad)
+    got = run_gpu(img8, ow, ow, np.float32, precision=m.STRICT, stage_mask=1)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "strict build differs from the oracle"
+    got8 = run_gpu(img8, ow, ow, np.uint8, precision=m.FP32, stage_mask=1)
+    assert np.array_equal(got8, O.float_to_unorm8(want)), lsb_stats(got8, O.float_to_unorm8(want))
+    gotf = run_gpu(img8, ow, ow, np.float32, precision=m.FP32, stage_mask=1)
+    assert np.abs(gotf[..., :3] - want[..., :3]).max() * 255.0 < 0.5 * m.BAND
+    want8q = O.fsr_pipeline_u8(img8, ow, ow, sharpness=0.9, quantize_intermediate=True)
+    got8q = run_gpu(img8, ow, ow, np.uint8, precision=m.FP32, sharpness=0.9, quantize_intermediate=1, fused=0)
+    mx, _ = lsb_stats(got8q, want8q)
+    assert mx <= 1, mx
+    got8s = run_gpu(img8, ow, ow, np.uint8, precision=m.STRICT, sharpness=0.9, quantize_intermediate=1, fused=0)
+    assert np.array_equal(got8s, want8q), lsb_stats(got8s, want8q)
