@@ -61,7 +61,9 @@ void PostProcessor::Join(hipStream_t user)
 {
     if (!auxStream_) return;
     (void)hipEventRecord(evJoin_, auxStream_);
+#ifndef OVRFSR_MUTATE_NO_JOIN /* mutation build (never shipped): proves tests/test_gpu_back_to_back.py notices a missing join edge */
     (void)hipStreamWaitEvent(user, evJoin_, 0);
+#endif
 }
 
 PostProcessor::~PostProcessor()

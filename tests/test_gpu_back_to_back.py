@@ -1,0 +1,102 @@
+"""Back-to-back launches of the multi-stream pipelines (GPU): a race detector for the ctx's stream graph.
+
+A masked pipeline runs two or three kernels concurrently on ctx-owned auxiliary streams (touching tiles || outside tiles, then
+RCAS on the joined result) and keeps its intermediate in ONE ctx-owned buffer; the unmasked two-kernel pipeline reuses that
+buffer too.  Every call must therefore order itself behind the previous call's readers: a missing event edge shows up only when
+calls are issued WITHOUT a host synchronisation in between, with different data -- exactly what bench.py's timed loop and a
+game's render thread do.  Here: two different input batches A and B, 24 calls alternating A, B, A, B ... into 24 distinct output
+buffers, one synchronisation OF THE CALLER'S STREAM at the end (the ABI's promise; a device-wide one would hide a missing join);
+every A result must equal the first A result (taken with full synchronisation before the
+loop), every B result the first B result, bit for bit.  Also through `ovrfsr_apply` (one image per call, alternating eyes).
+Mutation check (round 4, GPU): a library built with -DOVRFSR_MUTATE_NO_JOIN (the aux stream's join edge dropped) fails these tests."""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+FP32 = 0
+CASES = [
+    ("two-pass unmasked RGBA8", dict(radius=2.0, sharpness=0.9), np.uint8),
+    ("sorted two-pass, radius 0.5 (3 streams)", dict(radius=0.5, sharpness=0.9, debug_mode=1), np.uint8),
+    ("fused + outside, RGBA16F, radius 0.5 (2 streams)", dict(radius=0.5, sharpness=0.9), np.float16),
+    ("fused kernel on request, radius 0.6", dict(radius=0.6, sharpness=0.7, fused=1), np.uint8),
+    ("NVScaler + DirectCopy, radius 0.5", dict(radius=0.5, sharpness=0.9, use_nis=1), np.uint8),
+    ("EASU only, radius 0.4", dict(radius=0.4, stage_mask=1), np.uint8),
+    ("EASU only, radius 0.12: nearly every tile on the auxiliary stream", dict(radius=0.12, stage_mask=1), np.uint8),
+    ("NVScaler, radius 0.12: DirectCopy on the auxiliary stream is the long pole", dict(radius=0.12, use_nis=1, sharpness=0.5), np.uint8),
+]
+
+
+def _batch(dt, seed, n, iw, ih):
+    import torch
+    imgs = []
+    for i in range(n):
+        g = synth.structured_u8 if (seed + i) % 2 else synth.random_u8
+        a = g(iw, ih, 1000 * seed + i)
+        if dt == np.float16:
+            a = (a.astype(np.float32) / 255.0).astype(np.float16)
+        imgs.append(a)
+    return torch.from_numpy(np.stack(imgs)).cuda()
+
+
+@pytest.mark.parametrize("name,cfg,dt", CASES, ids=[c[0] for c in CASES])
+def test_back_to_back_batches_are_ordered(name, cfg, dt):
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh, n, calls = 960, 810, 1280, 1080, 6, 16
+    tdt = {np.uint8: torch.uint8, np.float16: torch.float16}[dt]
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **cfg)
+    try:
+        ins = [_batch(dt, 1, n, iw, ih), _batch(dt, 2, n, iw, ih)]
+        ref = []
+        for t in ins:
+            o = torch.zeros((n, oh, ow, 4), dtype=tdt, device="cuda")
+            pp.apply_batch(t, o)
+            torch.cuda.synchronize()
+            ref.append(o.clone())
+        assert not torch.equal(ref[0], ref[1])
+        outs = [torch.zeros((n, oh, ow, 4), dtype=tdt, device="cuda") for _ in range(calls)]
+        torch.cuda.synchronize()
+        snaps = []
+        for k in range(calls):            # no synchronisation between the calls
+            pp.apply_batch(ins[k & 1], outs[k])
+            # a consumer on the caller's stream right behind the call (the ABI's promise: the outputs are valid once the CALLER'S
+            # stream gets here -- a kernel still running on an auxiliary stream would be caught mid-write by this copy)
+            snaps.append(outs[k].clone())
+        torch.cuda.current_stream().synchronize()
+        for k in range(calls):
+            assert torch.equal(snaps[k].view(torch.uint8), ref[k & 1].view(torch.uint8)), "%s: the consumer of call %d saw other data than its reference" % (name, k)
+            assert torch.equal(outs[k].view(torch.uint8), ref[k & 1].view(torch.uint8)), "%s: call %d differs from its reference" % (name, k)
+    finally:
+        pp.close()
+
+
+@pytest.mark.parametrize("name,cfg,dt", CASES[:3], ids=[c[0] for c in CASES[:3]])
+def test_back_to_back_single_applies_are_ordered(name, cfg, dt):
+    """the reference's calling pattern: Apply(left), Apply(right), next frame ... with no synchronisation"""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh, frames = 480, 405, 640, 540, 12
+    tdt = {np.uint8: torch.uint8, np.float16: torch.float16}[dt]
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **cfg)
+    try:
+        src = _batch(dt, 3, 4, iw, ih)     # images 0,1 = frame type A (left, right); 2,3 = frame type B
+        ref = []
+        for i in range(4):
+            o = pp.apply(i & 1, src[i], out_dtype=tdt)
+            torch.cuda.synchronize()
+            ref.append(o.clone())
+        outs = []
+        torch.cuda.synchronize()
+        for f in range(frames):
+            for eye in (0, 1):
+                o = torch.zeros((oh, ow, 4), dtype=tdt, device="cuda")
+                pp.apply(eye, src[2 * (f & 1) + eye], out=o)
+                outs.append((2 * (f & 1) + eye, o.clone()))   # consumer on the caller's stream right behind the call
+        torch.cuda.current_stream().synchronize()
+        for k, (i, o) in enumerate(outs):
+            assert torch.equal(o.view(torch.uint8), ref[i].view(torch.uint8)), "%s: apply %d differs from its reference" % (name, k)
+    finally:
+        pp.close()
