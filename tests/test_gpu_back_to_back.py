@@ -100,3 +100,43 @@ def test_back_to_back_single_applies_are_ordered(name, cfg, dt):
             assert torch.equal(o.view(torch.uint8), ref[i].view(torch.uint8)), "%s: apply %d differs from its reference" % (name, k)
     finally:
         pp.close()
+
+
+def test_two_ctxs_on_two_streams_are_independent():
+    """"distinct ctxs are independent" (include/openvr_fsr_amd.h): two ctxs with different configs, each on its own caller stream,
+    calls interleaved from one host thread with no synchronisation; each ctx owns its intermediate, tile lists and auxiliary stream"""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh, n, calls = 960, 810, 1280, 1080, 4, 10
+    cfgs = [dict(radius=0.5, sharpness=0.9), dict(radius=2.0, sharpness=0.4)]
+    pps = [A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **c) for c in cfgs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    try:
+        ins = [_batch(np.uint8, 5, n, iw, ih), _batch(np.uint8, 6, n, iw, ih)]
+        torch.cuda.synchronize()
+        ref = {}
+        for c in range(2):
+            for b in range(2):
+                o = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
+                with torch.cuda.stream(streams[c]):
+                    pps[c].apply_batch(ins[b], o)
+                torch.cuda.synchronize()
+                ref[c, b] = o.clone()
+        outs, snaps = [], []
+        torch.cuda.synchronize()
+        for k in range(calls):
+            for c in range(2):
+                o = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
+                torch.cuda.current_stream().synchronize()          # the zero fill ran on the default stream
+                with torch.cuda.stream(streams[c]):
+                    pps[c].apply_batch(ins[(k + c) & 1], o)
+                    snaps.append(o.clone())
+                outs.append((c, (k + c) & 1, o))
+        for s in streams:
+            s.synchronize()
+        for i, (c, b, o) in enumerate(outs):
+            assert torch.equal(o, ref[c, b]), "ctx %d call %d differs" % (c, i)
+            assert torch.equal(snaps[i], ref[c, b]), "ctx %d call %d: consumer saw other data" % (c, i)
+    finally:
+        for p in pps:
+            p.close()
