@@ -140,3 +140,49 @@ def test_two_ctxs_on_two_streams_are_independent():
     finally:
         for p in pps:
             p.close()
+
+
+def test_two_host_threads_with_their_own_ctxs():
+    """no hidden global state: two host threads, each with its own ctx and caller stream on the SAME device, run different
+    pipelines at the same time (ctypes releases the GIL during the calls); each thread's results equal its references"""
+    import threading
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh, n, calls = 640, 540, 853, 720, 4, 40
+    cfgs = [dict(radius=0.5, sharpness=0.9), dict(radius=0.45, sharpness=0.6, use_nis=1)]
+    ins = [_batch(np.uint8, 7, n, iw, ih), _batch(np.uint8, 8, n, iw, ih)]
+    torch.cuda.synchronize()
+    errors = []
+
+    def work(c):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **cfgs[c])
+                try:
+                    ref = []
+                    for b in range(2):
+                        o = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
+                        pp.apply_batch(ins[b], o)
+                        s.synchronize()
+                        ref.append(o.clone())
+                    outs = [torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda") for _ in range(calls)]
+                    s.synchronize()
+                    for k in range(calls):
+                        pp.apply_batch(ins[k & 1], outs[k])
+                    s.synchronize()
+                    for k in range(calls):
+                        if not torch.equal(outs[k], ref[k & 1]):
+                            errors.append("thread %d call %d differs" % (c, k))
+                finally:
+                    pp.close()
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append("thread %d: %r" % (c, e))
+
+    ts = [threading.Thread(target=work, args=(c,)) for c in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
