@@ -164,3 +164,34 @@ def test_pipeline_u8_stages_and_alpha():
     assert np.array_equal(e, want)
     with pytest.raises(RuntimeError):
         O.fsr_pipeline_u8(img8, 64, 53, stages=2)  # sharpen-only needs equal sizes
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
+@pytest.mark.parametrize("ow,seed,mutated", [(160, 21, False), (240, 22, True), (156, 23, True)])
+def test_oracle_matches_reference_on_adversarial_patches(ow, seed, mutated):
+    """The content the round-4 adversarial search lives on (tools/debug/easu_err_search.py: cancelling gradient directions next to
+    the zero guard, extremes beside flats, mutated constant rows / columns) through the REFERENCE's own FsrEasuF / FsrRcasF compiled
+    for the CPU: the restatement is bit-identical there too -- the ill-conditioned direction blend is where an operator-order slip
+    in the oracle would show first."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("easu_err_search", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "tools", "debug", "easu_err_search.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.P = 8
+    rng = np.random.default_rng(seed)
+    base = m.fresh(rng)
+    g = 15
+    patches = [m.fresh(rng) if (not mutated or i % 3 == 0) else m.mutate(rng, m.mutate(rng, base)) for i in range(g * g)]
+    img8 = np.empty((8 * g, 8 * g, 4), np.uint8)
+    img8[..., 3] = 255
+    img8[..., :3] = np.stack(patches).reshape(g, g, 8, 8, 3).transpose(0, 2, 1, 3, 4).reshape(8 * g, 8 * g, 3)
+    img = O.unorm8_to_float(img8)
+    con = O.easu_con(8 * g, 8 * g, ow, ow)
+    centre, rad = O.mask_constants(ow, ow, 2.0, (0.5, 0.5, 0.5, 0.5), True, 0)
+    a = O.easu(img, ow, ow, con, centre, rad)
+    assert same_bits(a, O.ref_easu(img, ow, ow, con, centre, rad))
+    q = O.unorm8_to_float(O.float_to_unorm8(a))
+    rcon = O.rcas_con(0.9, 0)
+    assert same_bits(O.rcas(q, rcon, centre, rad), O.ref_rcas(q, rcon, centre, rad))
