@@ -89,7 +89,8 @@ def mutate(rng, p):
     return q
 
 
-SCALES = (("scale 3/4 (C2)", 4, 3), ("scale 0.77 (C4 shape)", 13, 10), ("scale 1/2", 2, 1), ("scale 2/3", 3, 2))
+SCALES = (("scale 3/4 (C2)", 4, 3), ("scale 0.77 (C4 shape)", 13, 10), ("scale 1/2", 2, 1), ("scale 2/3", 3, 2),
+          ("scale 1 (sharpen only)", 1, 1))   # index 4: PIPE=1 -> RCAS alone, NIS=1 -> NVSharpen (not part of the default sweep)
 
 
 def search(scale_index, gens, seed, nis=False, verbose=True):
@@ -165,7 +166,7 @@ def search(scale_index, gens, seed, nis=False, verbose=True):
 def main():
     gens = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    pick = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(len(SCALES))
+    pick = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(4)
     print("lib:", os.environ.get("OVRFSR_LIB", "(default)"), "EASU+RCAS" if NIS == "pipe" else "EASU of RGBA16F texels (x%g)" % HSCALE if NIS == "half" else "NVScaler" if NIS else "EASU", " %d generations, seed %d, band 2^-9 = %.3e byte" % (gens, seed, BAND))
     for i in pick:
         search(i, gens, seed, nis=NIS)
