@@ -186,3 +186,34 @@ def test_two_host_threads_with_their_own_ctxs():
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("cfg", [dict(radius=0.5, sharpness=0.9), dict(radius=2.0, sharpness=0.9), dict(radius=0.5, sharpness=0.9, use_nis=1)],
+                         ids=["sorted two-pass", "unmasked two-pass", "NVScaler masked"])
+def test_back_to_back_with_changing_batch_sizes(cfg):
+    """the ctx-owned intermediate follows the largest batch seen: growing it between two unsynchronised calls must not pull it
+    from under the kernels of the previous call"""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 640, 540, 853, 720
+    sizes = [2, 6, 3, 8, 1, 8, 5, 12, 4, 12]
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **cfg)
+    try:
+        src = _batch(np.uint8, 9, max(sizes), iw, ih)
+        ref = torch.zeros((max(sizes), oh, ow, 4), dtype=torch.uint8, device="cuda")
+        for i in range(max(sizes)):   # one image per call, eye parity as in a batch, fully synchronised
+            pp.apply_batch(src[i:i + 1], ref[i:i + 1], first_eye=i & 1)
+            torch.cuda.synchronize()
+        pp.reset()                    # the intermediate starts small again
+        outs = [torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda") for n in sizes]
+        torch.cuda.synchronize()
+        snaps = []
+        for n, o in zip(sizes, outs):
+            pp.apply_batch(src[:n], o)
+            snaps.append(o.clone())
+        torch.cuda.current_stream().synchronize()
+        for k, (n, o) in enumerate(zip(sizes, outs)):
+            assert torch.equal(o, ref[:n]), "call %d (batch of %d) differs" % (k, n)
+            assert torch.equal(snaps[k], ref[:n]), "call %d (batch of %d): consumer saw other data" % (k, n)
+    finally:
+        pp.close()
