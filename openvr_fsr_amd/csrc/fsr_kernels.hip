@@ -122,8 +122,7 @@ static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t
     }                                                                                                    \
     return hipErrorInvalidValue;
 
-// LDS of the fused kernel: EASU planes + 34x34 intermediate.  Product build with OVRFSR_FUSED_NARROW: the colour plane of
-// RGBA8 / RGBA16F input and a UNORM8 / half intermediate are planes of four halves (8 bytes per cell; fused_kernel).
+// LDS of the fused kernel: EASU planes + 34x34 intermediate (float4 cells)
 size_t fused_lds_bytes(int prec, int in_fmt, int mid_fmt, int cellsW, int cellsH)
 {
     size_t e = easu_lds_bytes(prec, in_fmt, cellsW, cellsH);
@@ -133,10 +132,6 @@ size_t fused_lds_bytes(int prec, int in_fmt, int mid_fmt, int cellsW, int cellsH
         const size_t ncell = (size_t)easu_fast_pitch(cellsW) * cellsH;
         // the luma plane doubles as the near-tie list region (fused_kernel) and is at least that large
         if (ncell * 4 < kFusedTieListBytes) e += kFusedTieListBytes;
-#if OVRFSR_FUSED_NARROW
-        if (in_fmt == FMT_RGBA8 || in_fmt == FMT_RGBA16F) e -= ncell * 8;
-        if (mid_fmt == FMT_RGBA8 || mid_fmt == FMT_RGBA16F) midCell = 8;
-#endif
     }
     (void)mid_fmt;
     return e + (size_t)(kTileW + 2) * (kTileH + 2) * midCell;

@@ -22,9 +22,6 @@ constexpr size_t kFusedLdsMax = 158 * 1024;
 #ifndef OVRFSR_FUSED_NT
 #define OVRFSR_FUSED_NT 256
 #endif
-#ifndef OVRFSR_FUSED_NARROW
-#define OVRFSR_FUSED_NARROW 0 // 1: half4 colour / intermediate planes in the product build's fused kernel (fused_lds_bytes)
-#endif
 constexpr int kFusedThreads = OVRFSR_FUSED_NT; // threads per workgroup of the product build's fused kernel (one 32x32 tile either way)
 // fused kernel: waves x sweeps x 64 near-tie entries (uint16), kept in the luma plane
 constexpr size_t kFusedTieListBytes = (size_t)(kFusedThreads / 64) * (((kTileW + 2) * (kTileH + 2) + kFusedThreads - 1) / kFusedThreads) * 64 * 2;
