@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates && ./valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #include <string>
 
@@ -144,6 +145,86 @@ MKERNEL(k_run2_fs, F1(a0, b0) F1(a1, b1) S1(a2, b2) S1(a3, b3) F1(a4, b4) F1(a5,
 MKERNEL(k_run2_fp, F1(a0, b0) F1(a1, b1) P1(p0, q0) P1(p1, q1) F1(a4, b4) F1(a5, b5) P1(p2, q2) P1(p3, q3))
 // the mix of the EASU pair block: 3 packed, 3 fast, 1 slow per 7 (+1 fast)
 MKERNEL(k_easu_like, P1(p0, q0) F1(a0, b0) P1(p1, q1) F1(a1, b1) S1(a2, b2) P1(p2, q2) F1(a3, b3) F1(a4, b4))
+
+// ---- round 5 (Next #1): longer runs, the s_nop the hazard recogniser inserts, and v_cndmask on VCC as compiled code uses it
+// runs of four and eight: is the F<->P (F<->S) interaction paid per class TRANSITION or per adjacent pair?
+MKERNEL(k_run4_fs, F1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) S1(a4, b4) S1(a5, b5) S1(a6, b6) S1(a7, b7))
+MKERNEL(k_run4_fp, F1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) P1(p0, q0) P1(p1, q1) P1(p2, q2) P1(p3, q3))
+#define F8BLK F1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) F1(a4, b4) F1(a5, b5) F1(a6, b6) F1(a7, b7)
+#define P8BLK P1(p0, q0) P1(p1, q1) P1(p2, q2) P1(p3, q3) P1(p0, q1) P1(p1, q2) P1(p2, q3) P1(p3, q0)
+#define S8BLK S1(a0, b0) S1(a1, b1) S1(a2, b2) S1(a3, b3) S1(a4, b4) S1(a5, b5) S1(a6, b6) S1(a7, b7)
+MKERNEL(k_run8_fp, F8BLK P8BLK)            // 16 per BODY
+MKERNEL(k_run16_fp, F8BLK F8BLK P8BLK P8BLK) // 32 per BODY
+MKERNEL(k_run8_fs, F8BLK S8BLK)
+// F S P cycles: does an S between F and P buy the F<->P transition back?
+MKERNEL(k_cyc_fsp, F1(a0, b0) S1(a1, b1) P1(p0, q0) F1(a2, b2) S1(a3, b3) P1(p1, q1) F1(a4, b4) S1(a5, b5) P1(p2, q2))
+// EASU's cell shape: 4 F (the two squared distances), 9 P; and the same with one S behind each of the first F's
+MKERNEL(k_cell_4f9p, F1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) P8BLK P1(p0, q2))
+MKERNEL(k_cell_4fs9p, F1(a0, b0) S1(a4, b4) F1(a1, b1) S1(a5, b5) F1(a2, b2) F1(a3, b3) P8BLK P1(p0, q2))
+MKERNEL(k_cell_4f2s9p, F1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) P8BLK P1(p0, q2) S1(a4, b4) S1(a5, b5))
+// s_nop 0 behind every VALU instruction (what the compiler puts between a v_rcp / v_pk_mul and its consumer): cost of the nop itself
+#define FN1(R, B) asm volatile("v_fma_f32 %0, %0, %1, %0\n\ts_nop 0" : "+v"(R) : "v"(B));
+#define PN1(R, Q) asm volatile("v_pk_fma_f32 %0, %0, %1, %0\n\ts_nop 0" : "+v"(R) : "v"(Q));
+MKERNEL(k_fma_snop, FN1(a0, b0) FN1(a1, b1) FN1(a2, b2) FN1(a3, b3) FN1(a4, b4) FN1(a5, b5) FN1(a6, b6) FN1(a7, b7))
+MKERNEL(k_fma_snop_1in8, FN1(a0, b0) F1(a1, b1) F1(a2, b2) F1(a3, b3) F1(a4, b4) F1(a5, b5) F1(a6, b6) F1(a7, b7))
+MKERNEL(k_pk_snop, PN1(p0, q0) PN1(p1, q1) PN1(p2, q2) PN1(p3, q3) PN1(p0, q1) PN1(p1, q2) PN1(p2, q3) PN1(p3, q0))
+// dependent chains (each instruction consumes the previous result): the hardware interlocks? cost of dependence vs 8 independent streams
+#define FD1(R, B) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(R) : "v"(B));
+MKERNEL(k_fma_dep, FD1(a0, b0) FD1(a0, b1) FD1(a0, b2) FD1(a0, b3) FD1(a0, b4) FD1(a0, b5) FD1(a0, b6) FD1(a0, b7))
+MKERNEL(k_pk_dep, P1(p0, q0) P1(p0, q1) P1(p0, q2) P1(p0, q3) P1(p0, q0) P1(p0, q1) P1(p0, q2) P1(p0, q3))
+// v_cndmask on VCC the way compiled code has it: a compare writes VCC, two independent fast ops sit in the hazard slots, the select
+// reads VCC (e32); the same with an SGPR-pair mask (e64).  4 VALU instructions per statement.
+#define CSEL_VCC(R, B, X, Y) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_fma_f32 %2, %2, %1, %2\n\tv_fma_f32 %3, %3, %1, %3\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(R), "+v"(B), "+v"(X), "+v"(Y) :: "vcc");
+#define CSEL_SGPR(R, B, X, Y) asm volatile("v_cmp_lt_f32 %4, %0, %1\n\tv_fma_f32 %2, %2, %1, %2\n\tv_fma_f32 %3, %3, %1, %3\n\tv_cndmask_b32 %0, %0, %1, %4" : "+v"(R), "+v"(B), "+v"(X), "+v"(Y), "=&s"(msk));
+MKERNEL(k_csel_vcc, CSEL_VCC(a0, b0, a4, a5) CSEL_VCC(a1, b1, a6, a7) CSEL_VCC(a2, b2, a4, a5) CSEL_VCC(a3, b3, a6, a7))
+__global__ __launch_bounds__(256) void k_csel_sgpr(float *out, int iters, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * .5f, b3 = a3 * .5f;
+    unsigned long long msk;
+    OVR_T0 for (int i = 0; i < iters; ++i) { REP8(CSEL_SGPR(a0, b0, a4, a5) CSEL_SGPR(a1, b1, a6, a7) CSEL_SGPR(a2, b2, a4, a5) CSEL_SGPR(a3, b3, a6, a7)) }
+    OVR_T1 out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3;
+}
+// v_cndmask reading a VCC nobody writes in the loop, and no clobber (no compiler-inserted s_nop): the instruction alone
+#define VCNDIN8                                                        \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a0) : "v"(b0)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a1) : "v"(b1)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a2) : "v"(b2)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a3) : "v"(b3)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a4) : "v"(b4)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a5) : "v"(b5)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a6) : "v"(b6)); \
+    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a7) : "v"(b7));
+KERNEL(k_cndmask_vcc_in, VCNDIN8)
+
+// v_cndmask on VCC, continued: 23 cycles for back-to-back e32 selects on VCC above, 4.1 with an SGPR-pair mask.  Is it the encoding
+// (VOP2 e32 reads VCC implicitly) or VCC itself, and does it survive other instructions in between?
+#define VCNDE64 \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a0) : "v"(b0)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a1) : "v"(b1)); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a2) : "v"(b2)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a3) : "v"(b3)); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a4) : "v"(b4)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a5) : "v"(b5)); \
+    asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a6) : "v"(b6)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a7) : "v"(b7));
+KERNEL(k_cnd_e64_vcc, VCNDE64)
+// one compare, five selects on it (NVScaler's `sh ? t1 : t0` groups), two fast ops: 8 VALU per statement
+#define CND5_VCC asm volatile("v_cmp_lt_f32 vcc, %0, %5\n\tv_fma_f32 %6, %6, %5, %6\n\tv_fma_f32 %7, %7, %5, %7\n\t" \
+    "v_cndmask_b32 %0, %0, %5, vcc\n\tv_cndmask_b32 %1, %1, %5, vcc\n\tv_cndmask_b32 %2, %2, %5, vcc\n\tv_cndmask_b32 %3, %3, %5, vcc\n\tv_cndmask_b32 %4, %4, %5, vcc" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(b0), "+v"(a6), "+v"(a7) :: "vcc");
+#define CND5_SGPR asm volatile("v_cmp_lt_f32 %8, %0, %5\n\tv_fma_f32 %6, %6, %5, %6\n\tv_fma_f32 %7, %7, %5, %7\n\t" \
+    "v_cndmask_b32 %0, %0, %5, %8\n\tv_cndmask_b32 %1, %1, %5, %8\n\tv_cndmask_b32 %2, %2, %5, %8\n\tv_cndmask_b32 %3, %3, %5, %8\n\tv_cndmask_b32 %4, %4, %5, %8" \
+    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(b0), "+v"(a6), "+v"(a7), "=&s"(msk));
+KERNEL(k_cnd5_vcc, CND5_VCC)
+__global__ __launch_bounds__(256) void k_cnd5_sgpr(float *out, int iters, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a6 = a0 + 6.f, a7 = a0 + 7.f, b0 = a0 * 0.5f;
+    unsigned long long msk;
+    OVR_T0 for (int i = 0; i < iters; ++i) { REP8(CND5_SGPR) }
+    OVR_T1 out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a6 + a7 + b0;
+}
+// selects on VCC separated by one / three fast ops
+#define CNDF(R, B, X) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_fma_f32 %2, %2, %1, %2" : "+v"(R), "+v"(B), "+v"(X));
+#define CNDFFF(R, B, X, Y, Z) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_fma_f32 %2, %2, %1, %2\n\tv_fma_f32 %3, %3, %1, %3\n\tv_fma_f32 %4, %4, %1, %4" : "+v"(R), "+v"(B), "+v"(X), "+v"(Y), "+v"(Z));
+KERNEL(k_cnd_alt_fma, CNDF(a0, b0, a4) CNDF(a1, b1, a5) CNDF(a2, b2, a6) CNDF(a3, b3, a7))
+KERNEL(k_cnd_3fma, CNDFFF(a0, b0, a4, a5, a6) CNDFFF(a1, b1, a7, a4, a5))
 KERNEL(k_rcp_f16, V8_1("v_rcp_f16"))
 KERNEL(k_sub_u32, V8_2("v_sub_u32"))
 KERNEL(k_lshrrev, V8_2("v_lshrrev_b32"))
@@ -342,8 +423,9 @@ static double run(kern_t k, float *d, int iters, int blocks)
     return ms;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const char *only = argc > 1 ? argv[1] : nullptr; // run only the rows whose name contains this string
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
@@ -376,6 +458,15 @@ int main()
         {"v_cndmask_b32 (sgpr mask)", k_cndmask_sgpr, 64}, {"v_mov_b32_dpp row_shr:1", k_mov_dpp_row_shr, 64},
         {"v_mov_b32_dpp wave_shr:1", k_mov_dpp_wave_shr, 64}, {"v_add_f32_dpp row_shr:1", k_add_f32_dpp, 64}, {"ds_bpermute_b32 (+wait)", k_ds_bpermute, 64},
         {"ds_read_b32", k_ds_read_b32, 64}, {"ds_read_b64", k_ds_read_b64, 64}, {"ds_read_b128", k_ds_read_b128, 64},
+        // round 5
+        {"runs FFFFSSSS", k_run4_fs, 64}, {"runs FFFFPPPP", k_run4_fp, 64}, {"runs F8 P8", k_run8_fp, 128}, {"runs F16 P16", k_run16_fp, 256}, {"runs F8 S8", k_run8_fs, 128},
+        {"cycle F S P", k_cyc_fsp, 72}, {"cell 4F 9P", k_cell_4f9p, 104}, {"cell F S F S F F 9P", k_cell_4fs9p, 120}, {"cell 4F 9P 2S", k_cell_4f2s9p, 120},
+        {"v_fma_f32 + s_nop 0 (each)", k_fma_snop, 64}, {"v_fma_f32, s_nop 0 behind 1 of 8", k_fma_snop_1in8, 64}, {"v_pk_fma_f32 + s_nop 0 (each)", k_pk_snop, 64},
+        {"v_fma_f32 dependent chain", k_fma_dep, 64}, {"v_pk_fma_f32 dependent chain", k_pk_dep, 64},
+        {"cmp->vcc, 2 fma, cndmask vcc (per instr)", k_csel_vcc, 128}, {"cmp->sgpr, 2 fma, cndmask sgpr (per instr)", k_csel_sgpr, 128},
+        {"v_cndmask_b32 vcc (no writer, no nop)", k_cndmask_vcc_in, 64},
+        {"v_cndmask_b32_e64 .., vcc (8 in a row)", k_cnd_e64_vcc, 64}, {"cmp->vcc, 2 fma, 5 cndmask vcc (per instr)", k_cnd5_vcc, 64}, {"cmp->sgpr, 2 fma, 5 cndmask sgpr (per instr)", k_cnd5_sgpr, 64},
+        {"alt cndmask vcc, fma", k_cnd_alt_fma, 64}, {"cndmask vcc + 3 fma", k_cnd_3fma, 64},
     };
     {
         unsigned long long *dt, ht[2] = {0, 0};
@@ -393,6 +484,7 @@ int main()
     }
     const int iters = 4000;
     for (auto &k : ks) {
+        if (only && !strstr(k.n, only)) continue;
         double ms = run(k.k, d, iters, blocks);
         // per SIMD: 8 waves each issuing iters*per_iter instructions
         double instr_per_simd = 8.0 * iters * k.per_iter;

@@ -10,6 +10,7 @@
 #   tools/variants/build.sh items    "-DOVRFSR_FUSED_ITEMS=1"      profiles/r04_fused_variants.txt   (=2 [-DOVRFSR_FUSED_SKIP_VRING]: prefetching form / strip bound)
 #   tools/variants/build.sh narrow   "-DOVRFSR_FUSED_NARROW=1"     profiles/r04_fused_variants.txt (5)
 #   tools/variants/build.sh compact  "-DOVRFSR_NIS_COMPACT"        profiles/r04_nis_compaction.txt   ([-DOVRFSR_NIS_DENSE_LANES=N])
+#   PATCHES=easu_fs_bundle tools/variants/build.sh fsb "-DOVRFSR_EASU_FS_BUNDLE [-DOVRFSR_EASU_OCC5]" | mme "-DOVRFSR_EASU_MM_EARLY"   profiles/r05_sched_ab.txt
 #   tools/variants/build.sh nishalf  "-DOVRFSR_NIS_HALF_LDS"       profiles/r03_nis_variants.txt
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
@@ -19,7 +20,7 @@ trap 'rm -rf "$S"' EXIT
 mkdir -p "$S/include" "$S/openvr_fsr_amd/csrc"
 cp "$ROOT"/include/*.h "$S/include/"
 cp "$ROOT"/openvr_fsr_amd/csrc/*.{inc,hip,h,hpp,cpp} "$ROOT"/openvr_fsr_amd/csrc/Makefile "$S/openvr_fsr_amd/csrc/"
-for P in "$ROOT"/tools/variants/*.patch; do (cd "$S" && patch -s -p1 < "$P"); done
+for P in ${PATCHES:-fsr_variants nis_variants}; do (cd "$S" && patch -s -p1 < "$ROOT/tools/variants/$P.patch"); done
 cd "$S/openvr_fsr_amd/csrc"
 if [ "$MODE" == "--syntax-only" ]; then
   for TU in fsr_kernels.hip nis_kernels.hip; do
