@@ -13,6 +13,10 @@
  * cheap deterministic pattern generated on the host once per device (gradients, a checker, a diagonal ramp, hashed noise),
  * uploaded before the timed region -- the kernels' cost does not depend on content.  --oversubscribe maps thread i to
  * device i % device_count (testing the N > 1 path on a box with fewer GPUs; not a scaling measurement).
+ * Self-verifying per device: after the timed region every shard downloads image 0 of its own output batch and checksums it; the main
+ * thread then has DEVICE 0 process every shard's image 0 (regenerated from the shard's seed) and compares the checksums.  A device
+ * whose kernels, per-device LDS attribute or ctx state went wrong fails the run by name (exit status 1, "parity_check" in the line);
+ * --corrupt-shard K (testing) flips one byte of shard K's downloaded image to show that it does.
  * Prints one JSON line.  bench.py remains the round driver's entry point; this is the C caller a node deployment would use.
  */
 #include <hip/hip_runtime_api.h>
@@ -27,8 +31,9 @@
 enum { IN_W = 1683, IN_H = 1869, OUT_W = 2244, OUT_H = 2492 };
 
 typedef struct {
-    int index, device, pairs, steps, warmup, fused;
+    int index, device, pairs, steps, warmup, fused, corrupt;
     float radius;
+    uint64_t out0_sum;     /* FNV-1a of image 0 of the output batch the timed calls wrote */
     pthread_barrier_t *gate;
     double t_start, t_end; /* host seconds around the timed region */
     float device_ms;       /* HIP events on the launch stream */
@@ -67,6 +72,15 @@ static void synth_eye(uint8_t *p, uint32_t seed)
         }
 }
 
+static uint64_t fnv1a(const uint8_t *p, size_t n)
+{
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; }
+    return h;
+}
+
+static uint32_t shard_seed0(int pairs, int index) { return 0x5EED0000u + 2u * (uint32_t)pairs * (uint32_t)index; }
+
 #define FAIL(s, ...) do { snprintf((s)->error, sizeof (s)->error, __VA_ARGS__); (s)->status = 1; } while (0)
 
 static void *run_shard(void *arg)
@@ -89,7 +103,7 @@ static void *run_shard(void *arg)
         /* the sub-batch of this device: global pairs [index * pairs, (index + 1) * pairs), seed 0x5EED0000 + 2 * pair + eye */
         h = (uint8_t *)malloc(in_bytes);
         for (uint32_t i = 0; i < n_img && h && !s->status; ++i) {
-            if (i < 4) synth_eye(h, 0x5EED0000u + 2u * (uint32_t)s->pairs * (uint32_t)s->index + i); /* four distinct images, then copies */
+            if (i < 4) synth_eye(h, shard_seed0(s->pairs, s->index) + i); /* four distinct images, then copies */
             const hipError_t e = i < 4 ? hipMemcpy((uint8_t *)d_in + in_bytes * i, h, in_bytes, hipMemcpyHostToDevice)
                                        : hipMemcpy((uint8_t *)d_in + in_bytes * i, (uint8_t *)d_in + in_bytes * (i & 3u), in_bytes, hipMemcpyDeviceToDevice);
             if (e != hipSuccess) FAIL(s, "upload of image %u", i);
@@ -122,6 +136,15 @@ static void *run_shard(void *arg)
     pthread_barrier_wait(s->gate);
     s->t_end = now_s();
     if (!s->status && hipEventElapsedTime(&s->device_ms, ev0, ev1) != hipSuccess) FAIL(s, "hipEventElapsedTime");
+    if (!s->status) { /* image 0 of what the timed calls wrote on THIS device */
+        uint8_t *o = (uint8_t *)malloc(out_bytes);
+        if (!o || hipMemcpy(o, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess) FAIL(s, "download of output image 0");
+        else {
+            if (s->corrupt) o[out_bytes / 2] ^= 0x10; /* --corrupt-shard: prove the comparison below notices */
+            s->out0_sum = fnv1a(o, out_bytes);
+        }
+        free(o);
+    }
     if (ctx) ovrfsr_destroy(ctx);
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
@@ -134,7 +157,7 @@ static void *run_shard(void *arg)
 
 int main(int argc, char **argv)
 {
-    int gpus = 1, pairs = 64, steps = 20, warmup = 5, oversubscribe = 0, fused = 0;
+    int gpus = 1, pairs = 64, steps = 20, warmup = 5, oversubscribe = 0, fused = 0, corrupt_shard = -1;
     float radius = 2.0f;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--oversubscribe")) oversubscribe = 1;
@@ -144,7 +167,8 @@ int main(int argc, char **argv)
         else if (i + 1 < argc && !strcmp(argv[i], "--steps")) steps = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--warmup")) warmup = atoi(argv[++i]);
         else if (i + 1 < argc && !strcmp(argv[i], "--radius")) radius = (float)atof(argv[++i]);
-        else { fprintf(stderr, "usage: %s [--gpus N] [--pairs P] [--steps K] [--warmup W] [--radius R] [--fused] [--oversubscribe]\n", argv[0]); return 2; }
+        else if (i + 1 < argc && !strcmp(argv[i], "--corrupt-shard")) corrupt_shard = atoi(argv[++i]);
+        else { fprintf(stderr, "usage: %s [--gpus N] [--pairs P] [--steps K] [--warmup W] [--radius R] [--fused] [--oversubscribe] [--corrupt-shard K]\n", argv[0]); return 2; }
     }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
@@ -157,6 +181,7 @@ int main(int argc, char **argv)
     pthread_t *th = (pthread_t *)calloc((size_t)gpus, sizeof *th);
     for (int i = 0; i < gpus; ++i) {
         sh[i].index = i; sh[i].device = i % count; sh[i].pairs = pairs; sh[i].steps = steps; sh[i].warmup = warmup; sh[i].radius = radius; sh[i].fused = fused;
+        sh[i].corrupt = i == corrupt_shard;
         sh[i].gate = &gate;
         pthread_create(&th[i], NULL, run_shard, &sh[i]);
     }
@@ -169,6 +194,37 @@ int main(int argc, char **argv)
         if (sh[i].t_end > t1) t1 = sh[i].t_end;
     }
     if (failed) return 1;
+    /* per-device parity: device 0 processes image 0 of every shard (same seed, same configuration) and must reproduce the bytes
+     * that shard's own device wrote in the timed region */
+    int *match = (int *)calloc((size_t)gpus, sizeof *match);
+    int parity_ok = 1;
+    {
+        const size_t in_bytes = (size_t)IN_W * IN_H * 4, out_bytes = (size_t)OUT_W * OUT_H * 4;
+        void *d_in = NULL, *d_out = NULL;
+        uint8_t *h = (uint8_t *)malloc(in_bytes), *o = (uint8_t *)malloc(out_bytes);
+        ovrfsr_ctx *ctx = NULL;
+        ovrfsr_config cfg;
+        ovrfsr_config_default(&cfg);
+        cfg.fsr_enabled = 1; cfg.sharpness = 0.9f; cfg.radius = radius; cfg.out_width = OUT_W; cfg.out_height = OUT_H;
+        if (fused) cfg.fused = 1;
+        int bad = !h || !o || hipSetDevice(sh[0].device) != hipSuccess || hipMalloc(&d_in, in_bytes) != hipSuccess ||
+                  hipMalloc(&d_out, out_bytes) != hipSuccess || ovrfsr_create(sh[0].device, &cfg, &ctx) != OVRFSR_OK;
+        const ovrfsr_image in0 = { d_in, IN_W, IN_H, IN_W * 4, OVRFSR_FORMAT_RGBA8_UNORM };
+        const ovrfsr_image out0 = { d_out, OUT_W, OUT_H, OUT_W * 4, OVRFSR_FORMAT_RGBA8_UNORM };
+        for (int i = 0; i < gpus && !bad; ++i) {
+            synth_eye(h, shard_seed0(pairs, i));
+            bad = hipMemcpy(d_in, h, in_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                  ovrfsr_apply_batch(ctx, 1, OVRFSR_EYE_LEFT, 1, &in0, in_bytes, &out0, out_bytes, NULL) != OVRFSR_OK ||
+                  hipDeviceSynchronize() != hipSuccess || hipMemcpy(o, d_out, out_bytes, hipMemcpyDeviceToHost) != hipSuccess;
+            if (!bad) match[i] = fnv1a(o, out_bytes) == sh[i].out0_sum;
+            if (!bad && !match[i]) { fprintf(stderr, "shard %d (device %d): image 0 differs from device %d's result for the same seed\n", i, sh[i].device, sh[0].device); parity_ok = 0; }
+        }
+        if (bad) { fprintf(stderr, "parity check could not run (%s)\n", ctx ? ovrfsr_last_error(ctx) : "setup"); parity_ok = 0; }
+        if (ctx) ovrfsr_destroy(ctx);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        free(h); free(o);
+    }
     const double wall = t1 - t0;
     printf("{\"metric\": \"stereo eye-pairs/sec at 1683x1869->2244x2492 (EASU+RCAS)\", \"value\": %.2f, \"unit\": \"eye-pairs/s\", "
            "\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"higher_is_better\": true, \"scaling\": \"weak\", "
@@ -177,8 +233,13 @@ int main(int argc, char **argv)
            (double)pairs * gpus * steps / wall, gpus, steps, warmup, wall / steps * 1e3, (double)radius, pairs,
            oversubscribe ? ", \"oversubscribed\": \"TEST RUN: shards share devices, not a scaling measurement\"" : "");
     for (int i = 0; i < gpus; ++i) printf("%s%.4f", i ? ", " : "", sh[i].device_ms / steps);
+    printf("]}, \"parity_check\": {\"ok\": %s, \"method\": \"image 0 of every shard's timed output batch (FNV-1a of its 22.4 MB) against device %d processing the "
+           "same seed\", \"per_shard\": [", parity_ok ? "true" : "false", sh[0].device);
+    for (int i = 0; i < gpus; ++i)
+        printf("%s{\"shard\": %d, \"device\": %d, \"checksum\": \"%016llx\", \"matches_device0\": %s}", i ? ", " : "", i, sh[i].device,
+               (unsigned long long)sh[i].out0_sum, match[i] ? "true" : "false");
     printf("]}}\n");
     pthread_barrier_destroy(&gate);
-    free(sh); free(th);
-    return 0;
+    free(sh); free(th); free(match);
+    return parity_ok ? 0 : 1;
 }

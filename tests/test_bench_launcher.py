@@ -92,13 +92,19 @@ import pytest  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(cmd, timeout=180):
+def _run(cmd, timeout=180, corrupt=None):
     env = dict(os.environ, OVRFSR_BENCH_SHARD_FACTORY="tests.mock_shard:make", PYTHONPATH=ROOT)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OVRFSR_MOCK_CORRUPT_SHARD"):
         env.pop(k, None)
+    if corrupt is not None:
+        env["OVRFSR_MOCK_CORRUPT_SHARD"] = str(corrupt)
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
-    assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    if corrupt is not None:   # a wrong shard: the line is still printed (it says which), the exit status is not 0
+        assert p.returncode != 0, "a corrupted shard must fail the run"
+        assert len(lines) == 1, lines
+        return json.loads(lines[0]), p.stderr
+    assert p.returncode == 0, p.stderr[-2000:]
     assert len(lines) == 1, "exactly ONE line on stdout, got %r" % lines   # the driver parses stdout as one JSON object
     return json.loads(lines[0])
 
@@ -114,6 +120,10 @@ def _check_line(d, n, steps, warmup, pairs):
     assert d["ms_per_step"] >= per_dev[-1] * 0.95
     assert d["value"] == pytest.approx(n * pairs * steps / (d["ms_per_step"] * 1e-3 * steps), rel=1e-3)
     assert d["config"]["pairs_per_gpu_per_step"] == pairs and d.get("mock_shards") is True
+    # every shard of the job proved image 0 of its own batch against the oracle: N records, in shard order, all ok
+    ps = d["parity_check"]["per_shard"]
+    assert [r["shard"] for r in ps] == list(range(n)) and all(r["ok"] and r["n_diff"] == 0 and r["image"] == 0 for r in ps)
+    assert d["parity_check"]["ok"] is True and d["parity_check"]["failed_shards"] == []
 
 
 @pytest.mark.timeout(300)
@@ -135,3 +145,27 @@ def test_driver_command_under_torch_distributed_run():
               "--master-port", str(port), "bench.py", "--gpus", str(n), "--steps", "5", "--warmup", "2"])
     _check_line(d, n, 5, 2, 64)
     assert "torchrun" in d["config"]["launcher"]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("k", [0, 5])
+def test_direct_run_fails_and_names_a_corrupted_shard(k):
+    """Shard k writes a wrong pixel (tests/mock_shard.py, OVRFSR_MOCK_CORRUPT_SHARD): the run exits non-zero, the line's
+    parity_check.per_shard has 8 entries with exactly entry k not ok, and stderr names shard k."""
+    d, err = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"], corrupt=k)
+    ps = d["parity_check"]["per_shard"]
+    assert len(ps) == 8 and [r["shard"] for r in ps if not r["ok"]] == [k] and ps[k]["max_lsb"] == 2
+    assert d["parity_check"]["ok"] is False and d["parity_check"]["failed_shards"] == [k]
+    assert "shard %d (device %d)" % (k, k) in err
+
+
+@pytest.mark.timeout(300)
+def test_torchrun_fails_and_names_a_corrupted_shard():
+    """The same under the driver's torchrun launch: rank 2's record reaches rank 0 through the gloo gather and fails the job."""
+    n, k = 4, 2
+    port = 29900 + (os.getpid() % 90)
+    d, err = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), "bench.py", "--gpus", str(n), "--steps", "3", "--warmup", "1"], corrupt=k)
+    ps = d["parity_check"]["per_shard"]
+    assert len(ps) == n and [r["shard"] for r in ps if not r["ok"]] == [k]
+    assert "shard %d (device %d)" % (k, k) in err

@@ -689,6 +689,16 @@ def test_c_node_driver(gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "eye-pairs/s" and d["value"] > 0
     assert len(d["config"]["per_device_ms_per_step"]) == 2 and all(m > 0 for m in d["config"]["per_device_ms_per_step"])
     assert d["config"]["pairs_per_gpu_per_step"] == 2 and "oversubscribed" in d["config"]
+    # self-verifying per device (round 5): image 0 of every shard's timed output against device 0 processing the same seed
+    ps = d["parity_check"]["per_shard"]
+    assert d["parity_check"]["ok"] is True and [p["shard"] for p in ps] == [0, 1] and all(p["matches_device0"] for p in ps)
+    assert ps[0]["checksum"] != ps[1]["checksum"]          # different seeds, different images
+    # ... and a shard whose output is wrong fails the run by name
+    r = subprocess.run([exe, "--gpus", "2", "--oversubscribe", "--pairs", "2", "--steps", "2", "--warmup", "1", "--corrupt-shard", "1"],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 1 and "shard 1 (device 0)" in r.stderr, (r.returncode, r.stderr)
+    bad = json.loads(r.stdout.strip().splitlines()[-1])["parity_check"]
+    assert bad["ok"] is False and [p["matches_device0"] for p in bad["per_shard"]] == [True, False]
     # the fused kernel (cfg.fused = 1) raises its dynamic-LDS attribute per (kernel, device): two ctxs, one process, masked tiles
     r = subprocess.run([exe, "--gpus", "2", "--oversubscribe", "--pairs", "2", "--steps", "2", "--warmup", "1", "--fused", "--radius", "0.5"],
                        capture_output=True, text=True, timeout=180)
