@@ -74,7 +74,20 @@ static hipError_t rcas_go(bool strict, const RcasArgs &a, dim3 grid, hipStream_t
     } else if constexpr (I == FMT_RGBA8 && O != FMT_RGB10A2) {
         if (dpp && unmasked) {
             const uint32_t tx = (uint32_t)(a.v.outW + kRcasDppTileW - 1) / kRcasDppTileW, ty = (uint32_t)(a.v.outH + kRcasDppTileH - 1) / kRcasDppTileH;
-            hipLaunchKernelGGL((ovrfsr_fast::rcas_dpp_kernel<O>), dim3(tx * ty, 1, grid.z), dim3(kThreads), 0, s, a);
+            // small launches: the grid is r = workgroups / kRcasResident rounds of the resident workgroups, the last one partly filled;
+            // half-height workgroups run ceil(2r) rounds of half the length (3 % more work per pixel).  One C2 eye image: r = 1.41,
+            // 2 rounds against 3 half rounds = 1.5 (14.4 instead of 15.5 us, profiles/r05_frame.txt); a batch: no difference, the
+            // 8-row form wins.  OVRFSR_RCAS_TH=16|32 forces one form (tuning)
+            static const int forced = [] { const char *e = std::getenv("OVRFSR_RCAS_TH"); return e ? std::atoi(e) : 0; }();
+            const uint64_t wgs = (uint64_t)tx * ty * grid.z;
+            const uint64_t full = (wgs + kRcasResident - 1) / kRcasResident, half = (2 * wgs + kRcasResident - 1) / kRcasResident;
+            const bool small = forced ? forced == 16 : (wgs < 16 * kRcasResident && 103 * half < 200 * full);
+            if (small) {
+                const uint32_t ty16 = (uint32_t)(a.v.outH + 15) / 16;
+                hipLaunchKernelGGL((ovrfsr_fast::rcas_dpp_kernel<O, false, 16>), dim3(tx * ty16, 1, grid.z), dim3(kThreads), 0, s, a);
+            } else {
+                hipLaunchKernelGGL((ovrfsr_fast::rcas_dpp_kernel<O>), dim3(tx * ty, 1, grid.z), dim3(kThreads), 0, s, a);
+            }
         } else if (dpp && a.tileList && a.spanRec && a.nSpans) {
             // mask-sorted form: the DPP kernel on 62-column segments of the runs of tiles touching the radius
             hipLaunchKernelGGL((ovrfsr_fast::rcas_dpp_kernel<O, true>), dim3(a.nSpans, 1, grid.z), dim3(kThreads), 0, s, a);

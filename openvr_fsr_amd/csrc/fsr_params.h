@@ -28,6 +28,7 @@ constexpr size_t kFusedTieListBytes = (size_t)(kFusedThreads / 64) * (((kTileW +
 constexpr int kOutsidePitch = 40; // outside_staged_kernel: floats per channel row of its planar LDS texel plane (>= 36 columns)
 constexpr int kRcasDppTileW = 62; // rcas_dpp_kernel: a wave = 64 consecutive columns, 62 stored (2 halo lanes)
 constexpr int kRcasDppTileH = 32; //                  4 waves x 8 rows per lane
+constexpr uint64_t kRcasResident = 8ull * 256; // workgroups of rcas_dpp_kernel an MI355X holds at once (8 per CU: 48 VGPRs, no LDS)
 
 // q = n / d for n*d < 2^32 as one scalar multiply-high: magic = floor(2^32/d) + 1 (0 = "d is 1").  Tile indices are
 // workgroup-uniform, but the hardware has no scalar divide: `tile / tilesX` costs ~20 VALU instructions per thread.

@@ -38,12 +38,21 @@ static inline float mad2(float a, float b, float c)
 
 PostProcessor::PostProcessor(int device, const ovrfsr_config &cfg) : device_(device), cfg_(cfg) {}
 
-hipStream_t PostProcessor::Fork(hipStream_t user)
+// The tiles outside the radius of a masked pass are independent of the tiles touching it: they can run on the ctx's auxiliary
+// stream beside the main kernel.  Whether that pays was re-measured in round 5 (profiles/r05_frame.txt):
+//   * RGBA8 sources (outside_staged_kernel: LDS-staged, persistent, streams at ~5 TB/s): NO.  In order on the caller's stream the
+//     step is faster at every batch size -- C2r 28.2 k against 27.9 k pairs/s at 128 images per call, 25.7 k against 24.3 k at 8 --
+//     and one eye image per call, the reference's own call pattern (one Apply per Submit), takes 35 us of GPU time instead of 44:
+//     the two cross-queue event waits of a fork / join pair cost ~10 us each, and two VALU- / HBM-hungry kernels sharing the CUs
+//     finish no sooner than one after the other.  (Rounds 2-3 overlapped them because the outside-tile kernel of that time was
+//     latency-bound; round 3 rebuilt it.)
+//   * other sources (easu_outside_kernel / nis_outside_kernel: per-pixel, latency-bound, 8 workgroups per CU of spare issue slots
+//     beside the fused kernel's 3): YES -- C5 13.9 k against 10.3 k pairs/s at 128 images per call, 12.8 k against 10.6 k at 2.
+// `overlap` is that decision (OverlapOutside); OVRFSR_SERIAL=1 / 0 forces in-order / forked launches (diagnostic).
+hipStream_t PostProcessor::Fork(hipStream_t user, bool overlap)
 {
-    // diagnostic: OVRFSR_SERIAL=1 keeps both kernels of a masked pass on the caller's stream (stand-alone kernel
-    // durations for profiling; the product default overlaps them)
-    static const bool serial = [] { const char *e = std::getenv("OVRFSR_SERIAL"); return e && e[0] == '1'; }();
-    if (serial) return user;
+    static const int serial = [] { const char *e = std::getenv("OVRFSR_SERIAL"); return e && e[0] == '1' ? 1 : e && e[0] == '0' ? 0 : -1; }();
+    if (serial == 1 || (serial < 0 && !overlap)) return user;
     if (!auxStream_) {
         if (hipStreamCreateWithFlags(&auxStream_, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&evFork_, hipEventDisableTiming) != hipSuccess ||
@@ -57,9 +66,9 @@ hipStream_t PostProcessor::Fork(hipStream_t user)
     return auxStream_;
 }
 
-void PostProcessor::Join(hipStream_t user)
+void PostProcessor::Join(hipStream_t user, hipStream_t aux)
 {
-    if (!auxStream_) return;
+    if (!auxStream_ || aux == user) return; // nothing was forked
     (void)hipEventRecord(evJoin_, auxStream_);
 #ifndef OVRFSR_MUTATE_NO_JOIN /* mutation build (never shipped): proves tests/test_gpu_back_to_back.py notices a missing join edge */
     (void)hipStreamWaitEvent(user, evJoin_, 0);
@@ -77,6 +86,13 @@ PostProcessor::~PostProcessor()
         if (q.start) (void)hipEventDestroy(q.start);
         if (q.end) (void)hipEventDestroy(q.end);
     }
+}
+
+bool PostProcessor::OverlapOutside(const ovrfsr_image &in) const
+{
+    // launch_easu_outside / launch_nis_outside take the LDS-staged kernel for RGBA8 sources when upscaling (outside_staged_ok)
+    const bool staged = in.format == OVRFSR_FORMAT_RGBA8_UNORM && in.width <= outputWidth_ && in.height <= outputHeight_;
+    return !staged;
 }
 
 int PostProcessor::Fail(int status, const std::string &what)
@@ -545,7 +561,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
         } else {
             EyePass passes[2];
             const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
-            hipStream_t aux = Fork(stream);
+            hipStream_t aux = Fork(stream, OverlapOutside(in));
             for (int p = 0; p < np && e == hipSuccess; ++p) {
                 NisArgs b = na;
                 const EyePass &ps = passes[p];
@@ -561,7 +577,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
                     e = launch_nis_outside((int)in.format, (int)out.format, b, nOutside_[ps.eye], ps.cnt, aux);
                 }
             }
-            Join(stream);
+            Join(stream, aux);
         }
         if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("NVScaler launch: ") + hipGetErrorString(e));
         return OVRFSR_OK;
@@ -574,7 +590,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
     } else {
         EyePass passes[2];
         const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
-        hipStream_t aux = Fork(stream);
+        hipStream_t aux = Fork(stream, OverlapOutside(in));
         for (int p = 0; p < np && e == hipSuccess; ++p) {
             EasuArgs b = a;
             const EyePass &ps = passes[p];
@@ -590,7 +606,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
                 e = launch_easu_outside((int)in.format, -1, (int)out.format, b, nOutside_[ps.eye], ps.cnt, aux);
             }
         }
-        Join(stream);
+        Join(stream, aux);
     }
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("EASU launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;
@@ -677,7 +693,7 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
     const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
     EyePasses(n, firstEye, alternate, midStride, midStride, midPasses); // same split, strides of the intermediate
     hipError_t e = hipSuccess;
-    hipStream_t aux = Fork(stream);
+    hipStream_t aux = Fork(stream, OverlapOutside(in));
     for (int p = 0; p < np && e == hipSuccess; ++p) {
         const EyePass &ps = passes[p];
         const EyePass &ms = midPasses[p];
@@ -711,7 +727,7 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
             e = launch_rcas(cfg_.precision, (int)mid.format, (int)out.format, rb, ps.cnt, stream, nInside_[eye]);
         }
     }
-    Join(stream);
+    Join(stream, aux);
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("mask-sorted EASU+RCAS launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;
 }
@@ -742,7 +758,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
         FillEasu(ea, in, inStride, out, outStride, firstEye, alternate);
         EyePass passes[2];
         const int np = EyePasses(n, firstEye, alternate, inStride, outStride, passes);
-        hipStream_t aux = Fork(stream);
+        hipStream_t aux = Fork(stream, OverlapOutside(in));
         for (int p = 0; p < np && e == hipSuccess; ++p) {
             const EyePass &ps = passes[p];
             FusedArgs fb = a;
@@ -760,7 +776,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
                 e = launch_easu_outside((int)in.format, (int)IntermediateFormat(), (int)out.format, eb, nOutside_[ps.eye], ps.cnt, aux);
             }
         }
-        Join(stream);
+        Join(stream, aux);
     }
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("fused EASU+RCAS launch: ") + hipGetErrorString(e));
     return OVRFSR_OK;

@@ -87,8 +87,9 @@ private:
     // a ctx-owned auxiliary stream, forked from and joined back into the caller's stream with events
     hipStream_t auxStream_ = nullptr;
     hipEvent_t evFork_ = nullptr, evJoin_ = nullptr;
-    hipStream_t Fork(hipStream_t user);
-    void Join(hipStream_t user);
+    bool OverlapOutside(const ovrfsr_image &in) const; // does a masked pass run its outside-tile kernel on the auxiliary stream?
+    hipStream_t Fork(hipStream_t user, bool overlap);
+    void Join(hipStream_t user, hipStream_t aux);
     int nisCellsW_ = 0, nisCellsH_ = 0;
 
     // ctx-owned device buffers: upscaledTexture / sharpenedTexture, PostProcessor.h:43-45,58-59

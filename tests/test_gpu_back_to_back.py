@@ -8,7 +8,9 @@ game's render thread do.  Here: two different input batches A and B, 24 calls al
 buffers, one synchronisation OF THE CALLER'S STREAM at the end (the ABI's promise; a device-wide one would hide a missing join);
 every A result must equal the first A result (taken with full synchronisation before the
 loop), every B result the first B result, bit for bit.  Also through `ovrfsr_apply` (one image per call, alternating eyes).
-Mutation check (round 4, GPU): a library built with -DOVRFSR_MUTATE_NO_JOIN (the aux stream's join edge dropped) fails these tests."""
+Mutation check (rounds 4-5, GPU): a library built with -DOVRFSR_MUTATE_NO_JOIN (the aux stream's join edge dropped) fails these tests
+(since round 5 only half-float sources fork; the RGBA8 cases run in order on the caller's stream and keep their place as
+ordering tests of the shared intermediate)."""
 import numpy as np
 import pytest
 
@@ -24,8 +26,12 @@ CASES = [
     ("fused kernel on request, radius 0.6", dict(radius=0.6, sharpness=0.7, fused=1), np.uint8),
     ("NVScaler + DirectCopy, radius 0.5", dict(radius=0.5, sharpness=0.9, use_nis=1), np.uint8),
     ("EASU only, radius 0.4", dict(radius=0.4, stage_mask=1), np.uint8),
-    ("EASU only, radius 0.12: nearly every tile on the auxiliary stream", dict(radius=0.12, stage_mask=1), np.uint8),
-    ("NVScaler, radius 0.12: DirectCopy on the auxiliary stream is the long pole", dict(radius=0.12, use_nis=1, sharpness=0.5), np.uint8),
+    ("EASU only, radius 0.12: nearly every tile outside", dict(radius=0.12, stage_mask=1), np.uint8),
+    ("NVScaler, radius 0.12: DirectCopy is the long pole", dict(radius=0.12, use_nis=1, sharpness=0.5), np.uint8),
+    # round 5: RGBA8 pipelines run their outside-tile kernel in order on the caller's stream (faster at every batch size); only sources
+    # whose outside tiles take the per-pixel kernel still fork onto the auxiliary stream -- half-float ones, as in the third case
+    ("EASU only, RGBA16F, radius 0.3 (forked)", dict(radius=0.3, stage_mask=1), np.float16),
+    ("NVScaler + DirectCopy, RGBA16F, radius 0.4 (forked)", dict(radius=0.4, use_nis=1, sharpness=0.6), np.float16),
 ]
 
 
