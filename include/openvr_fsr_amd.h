@@ -65,19 +65,21 @@ typedef enum ovrfsr_format {
 
 /* Arithmetic the kernels run in.  The reference only ever compiles the fp32 bodies
  * (`//#define A_HALF`, src/fsr/fsr_easu.hlsl:3).
- *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp): the product build.  Its quantised EASU stores
- *                (the UNORM8 / half intermediate, an EASU-only UNORM8 output) are nevertheless the STRICT build's -- EMPIRICALLY bit for
- *                bit: pixels whose result lies within 2^-9 byte (for half stores: within 2^-6 of a half spacing -- a band that
- *                follows the value's binade --, for values >= xmin = 0.25 / 0.5 derived from the sharpness: a flipped half-ulp below
- *                xmin stays under 1e-3 behind RCAS's largest gain) of a rounding boundary are re-resolved in the
- *                reference's operator order (near-tie guard).  The band is 6.7x the largest distance between
- *                the two evaluations that a DIRECTED search could produce (2.9e-4 byte: tools/debug/easu_err_search.py evolves
- *                texel patches to maximise it; the filter's one ill-conditioned step, the direction blend, is evaluated in
- *                the reference's order for that reason -- the contracted form reached three bands) and 3x the largest found
- *                on images (tools/debug/easu_err.py); it is not a derived bound.  The half band holds with the same margin for
- *                unit-range RGBA16F images (0.2 of the band under the search); for HDR texels (taps 40x the output value: 2.9
- *                bands) the error follows the largest tap, the band the output: such a half store may be one half-ulp off.  Float
- *                outputs differ by <= 3e-6, UNORM8 pipeline outputs by <= 1 LSB
+ *   FP32         fp32 math, FMA contraction allowed, hardware rcp (<= 1 ulp): the product build.  Its quantised EASU stores (the UNORM8 /
+ *                half intermediate of a pipeline, an EASU-only UNORM8 output) are nevertheless the STRICT build's, bit for bit: a pixel whose
+ *                re-associated result lies within 2^-9 byte of a UNORM8 rounding boundary -- for half stores within 2^-6 of a half spacing,
+ *                that band scaled with the largest texel of the tile's input footprint where it exceeds 1 (HDR: the re-association error
+ *                follows the largest tap, not the output), for values >= xmin = 0.25 / 0.5 derived from the sharpness (a flipped half-ulp
+ *                below xmin stays under 1e-3 behind RCAS's largest gain) -- is re-resolved in the reference's operator order (near-tie
+ *                guard).  This is AUDITED, not derived: an audit build of the same kernels (-DOVRFSR_TIE_AUDIT) re-resolves every
+ *                pixel in reference order on the device and counts the unlisted pixels whose stored value differs -- 0 in 2.6e9 pixels over
+ *                every configuration, structured / random / extreme content, RGBA16F content up to 40x the unit range, and the candidates of
+ *                a directed search that maximises the distance between the two evaluations; the largest distance met is 3.0e-4 byte, 0.15 of
+ *                the band (profiles/r05_tie_audit.txt, tests/test_gpu_adversarial.py).  A first-order worst-case bound of that distance is
+ *                two orders of magnitude above the band (same file, section 5): the filter's one ill-conditioned step, the direction blend, is
+ *                evaluated in the reference's order for that reason, the rest is rounding noise that no norm bound captures.  A violation,
+ *                should one exist, is one LSB (one half-ulp) of one intermediate pixel.  Float outputs differ by <= 3e-6, UNORM8 pipeline
+ *                outputs by <= 1 LSB, half pipeline outputs by <= 1e-3 on unit-range images and by <= one half-ulp of the value beyond
  *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
  *                to the CPU oracle; a validation build, not a fast one
  * There is no packed-half arithmetic mode (value 1 was reserved for one in ABI 1 and is rejected with

@@ -7,6 +7,7 @@
 #include <memory>
 #include <new>
 #include "postprocessor.hpp"
+#include "fsr_launch.h"
 #include "nis_tables.h"
 
 struct ovrfsr_ctx {
@@ -42,6 +43,16 @@ constexpr uint32_t kMaxExtent = 16384; // same limit CheckImage puts on caller i
 extern "C" {
 
 OVRFSR_API uint32_t ovrfsr_abi_version(void) { return OVRFSR_ABI_VERSION; }
+
+#ifdef OVRFSR_TIE_AUDIT
+// AUDIT BUILDS ONLY (-DOVRFSR_TIE_AUDIT; not part of the ABI, not declared in include/openvr_fsr_amd.h, absent from the shipped library):
+// the current device's near-tie audit counters {audited, listed, flips, small-channel half differences, max distance bytes (fp32 bits),
+// max distance half spacings (fp32 bits)} -- see g_ovrfsr_tie_audit in fsr_kernels.hip.  tools/debug/tie_audit.py drives it.
+OVRFSR_API int ovrfsr_debug_tie_audit(unsigned long long counts[6], int reset)
+{
+    return ovrfsr::tie_audit_read(counts, reset != 0) == hipSuccess ? OVRFSR_OK : OVRFSR_ERR_HIP;
+}
+#endif
 
 OVRFSR_API void ovrfsr_config_default(ovrfsr_config *cfg)
 {

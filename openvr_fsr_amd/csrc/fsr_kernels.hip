@@ -7,6 +7,16 @@
 #include "fsr_params.h"
 #include "fsr_launch.h"
 
+#ifdef OVRFSR_TIE_AUDIT
+// AUDIT BUILD (-DOVRFSR_TIE_AUDIT, never shipped): every pixel the product EASU resolves is resolved a second time in the reference's
+// operator order, and what the product build stores is compared with what the strict build would store.  Counters, per device:
+//   [0] pixels audited   [1] pixels the near-tie guard listed (re-resolved in reference order: equal by construction)
+//   [2] FLIPS: pixels NOT listed whose stored UNORM8 bytes / guarded halves differ from the strict build's  -- the guard's claim is [2] == 0
+//   [3] unlisted pixels whose half store differs in a channel BELOW xmin (outside the guard's contract: a flipped half-ulp there stays under 1e-3)
+//   [4] max |product - strict| over all audited channels, fp32 bit pattern: bytes (UNORM8 stores) ...  [5] ... or half spacings (half stores)
+__device__ unsigned long long g_ovrfsr_tie_audit[6];
+#endif
+
 namespace ovrfsr_fast {
 #define OVRFSR_STRICT 0
 #pragma clang fp contract(fast)
@@ -311,6 +321,23 @@ hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t s
 {
     hipLaunchKernelGGL(bgra_to_rgba_kernel, dim3((w + 255) / 256, h, batch), dim3(256), 0, s, src, srcPitch, srcStride, dst, w, h);
     return hipGetLastError();
+}
+
+// audit build: read (and optionally clear) the current device's counters; product build: hipErrorNotSupported
+hipError_t tie_audit_read(unsigned long long out[6], bool reset)
+{
+#ifdef OVRFSR_TIE_AUDIT
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ovrfsr_tie_audit), 6 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_ovrfsr_tie_audit), z, sizeof z);
+    }
+    return e;
+#else
+    (void)out; (void)reset;
+    return hipErrorNotSupported;
+#endif
 }
 
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)

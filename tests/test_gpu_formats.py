@@ -205,3 +205,43 @@ def test_half_pipeline_hdr_values(gpu, scale):
         err = np.abs(got[ok] - w32[ok])
         assert err.max() <= 1e-3 * max(1.0, scale), (scale, fused, float(err.max()))
         assert np.array_equal(np.isfinite(got), ok)
+
+
+def _hdr_image(iw, ih, seed, scale, kind):
+    """RGBA16F eye image reaching `scale`: the structured generator scaled as a whole, or a DARK image (values <= 1) with sparse
+    highlights at `scale` -- taps tens of times the output value, the case the binade-relative band of round 4 did not cover"""
+    base = synth.structured_u8(iw, ih, seed).astype(np.float32) / 255.0
+    if kind == "scaled":
+        img = base * np.float32(scale)
+    else:
+        rng = np.random.default_rng(seed)
+        img = base.copy()
+        hot = rng.random((ih, iw)) < 0.02
+        img[hot, :3] = np.float32(scale) * rng.uniform(0.5, 1.0, (int(hot.sum()), 3)).astype(np.float32)
+    img = img.astype(np.float16)
+    img[..., 3] = np.float16(1.0)
+    return img
+
+
+@pytest.mark.parametrize("scale,kind", [(1.0, "scaled"), (6.0, "scaled"), (40.0, "scaled"), (6.0, "highlights"), (40.0, "highlights"), (400.0, "highlights")])
+def test_half_intermediate_is_the_strict_builds_also_on_hdr(gpu, scale, kind, monkeypatch):
+    """Round 5 (VERDICT r4 Next #5): the HALF near-tie guard scales its band with the largest texel of the tile's footprint, so the
+    product build's half intermediate equals the strict build's BIT FOR BIT for every channel >= xmin on HDR content too -- read here
+    as the output of an EASU-only RGBA16F pass with the guard forced on from 0.5 (OVRFSR_TIE_HALF_MIN, the value the sharpness-0.9
+    pipeline uses).  Channels below xmin are outside the guard's contract (a flipped half-ulp there stays under 1e-3 behind RCAS's
+    largest gain): they may differ by one half-ulp, no more."""
+    from tests.util import run_gpu
+    monkeypatch.setenv("OVRFSR_TIE_HALF_MIN", "0.5")
+    iw, ih, ow, oh = 474, 360, 632, 480
+    for seed in (5, 6):
+        imgh = _hdr_image(iw, ih, seed, scale, kind)
+        kw = dict(stage_mask=1, radius=2.0)
+        s = run_gpu(imgh, ow, oh, np.float16, precision=STRICT, **kw)
+        p = run_gpu(imgh, ow, oh, np.float16, precision=FP32, **kw)
+        s32, p32 = s[..., :3].astype(np.float32), p[..., :3].astype(np.float32)
+        guarded = np.maximum(s32, p32) >= 0.5
+        differ = s[..., :3].view(np.uint16) != p[..., :3].view(np.uint16)
+        assert guarded.sum() > 1000, "the case must exercise the guard"
+        assert not (differ & guarded).any(), "%d guarded half stores differ from the strict build (scale %g, %s)" % (int((differ & guarded).sum()), scale, kind)
+        ulp = np.maximum(np.abs(s32), 2.0 ** -14) * 2.0 ** -10        # one half spacing (upper bound inside the binade)
+        assert (np.abs(s32 - p32)[differ] <= ulp[differ] * 1.0001).all()

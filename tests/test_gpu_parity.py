@@ -373,7 +373,9 @@ def test_c4_c5_shapes_properties(gpu):
     assert np.array_equal(got, want.astype(np.float16))
     got = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5).astype(np.float32)
     err = np.abs(got - want.astype(np.float16).astype(np.float32))
-    assert (err <= 1e-3).mean() >= 0.999 and err.max() <= 2e-2, (float((err <= 1e-3).mean()), float(err.max()))
+    # the contract (north_star): max-abs <= 1e-3 on every value, none above -- one half-ulp in [1, 2) is 9.77e-4, the largest a unit-range
+    # half output can be off by when its intermediate is the strict build's (near-tie guard)
+    assert err.max() <= 1e-3, (float(err.max()), int((err > 1e-3).sum()))
 
 
 # ------------------------------------------------------------------------------------------------

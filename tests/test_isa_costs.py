@@ -78,7 +78,7 @@ def test_table_of_the_shipped_library(tmp_path):
     assert n == len(doc["kernels"]) and n >= 100
     cfg = I.find_kernel(doc, "void ovrfsr_fast::easu_fast_kernel<0, 0, 28, false>(ovrfsr::EasuArgs)")
     assert cfg is not None and len(cfg["blocks"]) > 20 and cfg["exits"]
-    for name in ("ovrfsr_fast::rcas_dpp_kernel<0, false>(ovrfsr::RcasArgs)", "ovrfsr_fast::nis_scaler_kernel<0, 0, 32>(ovrfsr::NisArgs)",
+    for name in ("ovrfsr_fast::rcas_dpp_kernel<0, false, 32>(ovrfsr::RcasArgs)", "ovrfsr_fast::nis_scaler_kernel<0, 0, 32>(ovrfsr::NisArgs)",
                  "ovrfsr_fast::fused_kernel<1, 1, 1, 32, 256>(ovrfsr::FusedArgs)"):
         assert I.find_kernel(doc, name) is not None, name
     # every edge joins existing blocks, the entry block is block 0, strict kernels are not in the table

@@ -15,7 +15,13 @@ there is no guard on that path: its contract is <= 1 LSB, and the distance shows
 HALF=1 [HSCALE=s] searches EASU on RGBA16F texels half(b/255*s) against the HALF guard's relative band (outputs >= 0.5).
 PIPE=1 searches the EASU -> RCAS pipeline's float output (10x10 patches): with the intermediate bit-identical, RCAS's own distance.
 
-Usage: [NIS=1 | PIPE=1] python tools/debug/easu_err_search.py [generations=400] [seed=1] [scales=0,1,2,3]      (GPU; OVRFSR_LIB selects the library)
+AUDIT=1 (with OVRFSR_LIB pointing at an audit build, tools/build_variant.sh audit "-DOVRFSR_TIE_AUDIT"): every generation's image is ALSO run
+through the guarded store path (EASU-only UNORM8 output; RGBA16F output with the half guard on from 0.5 for HALF=1), where the audit build
+re-resolves every pixel in reference order and counts FLIPS -- unlisted pixels whose stored value differs from the strict build's.  The
+search's objective stays the distance: a flip needs |product - strict| > band at a pixel the guard did not list, so driving the distance up
+IS the search for a flip; the audit says whether any candidate on the way produced one.
+
+Usage: [NIS=1 | PIPE=1 | HALF=1 [HSCALE=s]] [AUDIT=1] python tools/debug/easu_err_search.py [generations=400] [seed=1] [scales=0,1,2,3]      (GPU; OVRFSR_LIB selects the library)
 """
 import os
 import sys
@@ -29,6 +35,24 @@ sys.path.insert(0, ROOT)
 STRICT, FP32 = 2, 0
 NIS = "pipe" if os.environ.get("PIPE", "0") == "1" else "half" if os.environ.get("HALF", "0") == "1" else os.environ.get("NIS", "0") == "1"
 HSCALE = float(os.environ.get("HSCALE", "1.0"))   # HALF=1: texel = half(b / 255 * HSCALE)
+AUDIT = os.environ.get("AUDIT", "0") == "1"
+if AUDIT and NIS == "half":
+    os.environ.setdefault("OVRFSR_TIE_HALF_MIN", "0.5")
+
+
+def audit_counters(reset=False):
+    """the audit build's device counters (see g_ovrfsr_tie_audit, fsr_kernels.hip); None with a product library"""
+    import ctypes
+    import openvr_fsr_amd as A
+    fn = getattr(A.library(), "ovrfsr_debug_tie_audit", None)
+    if fn is None:
+        return None
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    buf = (ctypes.c_ulonglong * 6)()
+    if fn(buf, 1 if reset else 0) != 0:
+        return None
+    f = lambda bits: float(np.uint32(bits & 0xffffffff).view(np.float32))  # noqa: E731
+    return {"audited": buf[0], "listed": buf[1], "flips": buf[2], "small_half_diffs": buf[3], "max_dist_bytes": f(buf[4]), "max_dist_half_spacings": f(buf[5])}
 P = 8   # patch edge in texels (set by search(): 8 for EASU, 12 for NVScaler; 30 / 20 patches per image edge -> 240 x 240 texels,
         # divisible by 3 and 10: exact output sizes at every scale of SCALES)
 BAND = 2.0 ** -9
@@ -132,6 +156,8 @@ def search(scale_index, gens, seed, nis=False, verbose=True):
         src = (img.astype(np.float32) * np.float32(HSCALE / 255.0)).astype(np.float16) if half else img
         fs = run_gpu(src, ow, oh, np.float32, precision=STRICT, **kw)
         fp = run_gpu(src, ow, oh, np.float32, precision=FP32, **kw)
+        if AUDIT and (half or not nis):   # the guarded store path of the same candidates (counted on the device by an audit build)
+            run_gpu(src, ow, oh, np.float16 if half else np.uint8, precision=FP32, **kw)
         if half:
             a, b = fp[..., :3].astype(np.float64), fs[..., :3].astype(np.float64)
             band = 2.0 ** (np.floor(np.log2(np.maximum(b, 2.0 ** -14))) - 10 - 6)   # 2^-6 of the half spacing of the reference value
@@ -168,8 +194,15 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     pick = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(4)
     print("lib:", os.environ.get("OVRFSR_LIB", "(default)"), "EASU+RCAS" if NIS == "pipe" else "EASU of RGBA16F texels (x%g)" % HSCALE if NIS == "half" else "NVScaler" if NIS else "EASU", " %d generations, seed %d, band 2^-9 = %.3e byte" % (gens, seed, BAND))
+    if AUDIT:
+        assert audit_counters(reset=True) is not None, "AUDIT=1 needs an audit build (OVRFSR_LIB=ab/audit.so)"
     for i in pick:
         search(i, gens, seed, nis=NIS)
+    if AUDIT:
+        c = audit_counters()
+        print("AUDIT: %d pixels of the search's candidates audited on their guarded store path, %d listed, FLIPS %d, small-channel half differences %d, "
+              "max distance %.3e byte / %.3e half spacings" % (c["audited"], c["listed"], c["flips"], c["small_half_diffs"], c["max_dist_bytes"], c["max_dist_half_spacings"]))
+        sys.exit(1 if c["flips"] else 0)
 
 
 if __name__ == "__main__":
