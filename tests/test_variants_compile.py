@@ -37,6 +37,10 @@ PATCHED = [
     ("compact", "-DOVRFSR_NIS_COMPACT"),
     ("nishalf", "-DOVRFSR_NIS_HALF_LDS"),
     ("plain", ""),
+    # round 5's scheduling experiments (profiles/r05_sched_ab.txt): each its own patch
+    ("soa", "-DOVRFSR_EASU_SOA", "easu_soa"),
+    ("fsb", "-DOVRFSR_EASU_FS_BUNDLE -DOVRFSR_EASU_OCC5", "easu_fs_bundle"),
+    ("mme", "-DOVRFSR_EASU_MM_EARLY", "easu_fs_bundle"),
 ]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
@@ -50,8 +54,9 @@ def _syntax(tu, flags):
     return (tu, flags, r.returncode, r.stderr[-2000:])
 
 
-def _patched(name, flags):
-    r = subprocess.run([os.path.join(ROOT, "tools", "variants", "build.sh"), name, flags, "--syntax-only"], capture_output=True, text=True)
+def _patched(name, flags, patches=None):
+    env = dict(os.environ, PATCHES=patches) if patches else None
+    r = subprocess.run([os.path.join(ROOT, "tools", "variants", "build.sh"), name, flags, "--syntax-only"], capture_output=True, text=True, env=env)
     return (name, flags, r.returncode, (r.stdout + r.stderr)[-2000:])
 
 
