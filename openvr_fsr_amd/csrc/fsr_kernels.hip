@@ -222,8 +222,9 @@ hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const Fu
     // OVRFSR_FUSED_LDS_PAD=<bytes> (diagnostic): extra dynamic LDS nobody touches -> fewer workgroups per CU; measures how the kernel's
     // throughput follows its occupancy (profiles/r04_fused_variants.txt) before anyone rebuilds its planes to gain a workgroup
     static const size_t pad = [] { const char *e = std::getenv("OVRFSR_FUSED_LDS_PAD"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 0); }();
-    size_t lds = fused_lds_bytes(prec, in_fmt, mid_fmt, a.cellsW, a.cellsH) + pad;
-    if (lds > kFusedLdsMax) lds = kFusedLdsMax;
+    const size_t need = fused_lds_bytes(prec, in_fmt, mid_fmt, a.cellsW, a.cellsH);
+    if (need > kFusedLdsMax) return hipErrorInvalidValue; // never launch with less LDS than the plane layout assumes (callers pre-check: PrepareResources)
+    const size_t lds = need + pad > kFusedLdsMax ? kFusedLdsMax : need + pad; // only the diagnostic pad is clamped
     OVRFSR_DISPATCH_FMT3(fused_go, mid_fmt, strict, a, grid, lds, s)
 }
 

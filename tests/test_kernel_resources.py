@@ -108,11 +108,12 @@ def test_c5_pair_fits_one_simd(kernels):
     worst_o = max(_alloc(v["vgpr_count"]) for v in outside.values())
     assert 3 * worst_f + 5 * worst_o <= 512
     # LDS: three workgroups per CU.  Dynamic LDS at C5 (2370 -> 3160: the 34-row block's footprint is 29 texel rows at pitch 32):
-    # colour + analysis + luma planes (36 B per cell) + kLumPadRows luma rows + the 34x34 float4 intermediate; static LDS = the
-    # 34-entry row and column tables of stage 1 (round 4) and the per-wave list counters
+    # colour + analysis + luma planes (36 B per cell) + kLumPadRows luma rows + the 34x34 float4 intermediate; static LDS of the shipped
+    # kernel = the per-wave list counters and the footprint-maximum word of the HDR half guard (32 B; the 1.1 KB row / column tables belong to
+    # the item-walking measurement variant, tools/variants/fsr_variants.patch, not to this library)
     dynamic_c5 = 32 * 29 * 36 + 32 * 5 * 4 + 34 * 34 * 16
     for k, v in fused.items():
-        assert v["group_segment_fixed_size"] <= 1280, (k, v["group_segment_fixed_size"])
+        assert v["group_segment_fixed_size"] <= 64, (k, v["group_segment_fixed_size"])
         assert 3 * (dynamic_c5 + v["group_segment_fixed_size"]) <= 160 * 1024, (k, v["group_segment_fixed_size"])
 
 
