@@ -15,7 +15,7 @@ for W in $WL; do
              "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
     i=$((i+1))
     rm -rf /tmp/sqv_${W}_$i
-    rocprofv3 --pmc $SET --output-format csv -d /tmp/sqv_${W}_$i -o pmc -- python bench.py --no-cpu --no-extras --no-verify --pmc off --steps 2 --warmup 1 --pairs 4 --workload $W > /dev/null 2>&1
+    rocprofv3 --pmc $SET --output-format csv -d /tmp/sqv_${W}_$i -o pmc -- python bench.py --no-cpu --no-extras --no-verify --pmc off --steps 2 --warmup 1 --pairs 4 --workload $W ${PMC_EXTRA_ARGS:-} > /dev/null 2>&1
     F=$(find /tmp/sqv_${W}_$i -name '*counter_collection.csv' | head -1)
     [ -n "$F" ] && python - "$F" "$W" >> "$OUT/sq_$W.txt" <<'PY'
 import csv, sys, collections, re
