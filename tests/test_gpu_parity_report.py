@@ -4,7 +4,7 @@ Each case runs the HIP path through the C ABI and the CPU oracle on the same see
   max_abs   largest |difference| on float outputs (unit domain)
   max_lsb   largest byte difference on UNORM8 outputs
   n_diff    how many channel values differ at all, of n_total
-into gpurun_out/parity_r04.json (merged back from the GPU box; the copy under profiles/ is the committed record).
+into gpurun_out/parity_r05.json (merged back from the GPU box; the copy under profiles/ is the committed record).
 The asserts are the stated tolerances:
   strict build   bit-exact everywhere (n_diff == 0)
   product build  float outputs max-abs <= 1e-3 (north_star), measured ~3e-6;
@@ -36,7 +36,7 @@ def _write_report():
         return
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "parity_r04.json"), "w") as f:
+    with open(os.path.join(out_dir, "parity_r05.json"), "w") as f:
         json.dump({"note": "HIP path vs CPU oracle at full BASELINE sizes; written by tests/test_gpu_parity_report.py",
                    "records": _RECORDS}, f, indent=1)
 
@@ -57,7 +57,7 @@ def _rec(config, build, content, output, got, want):
         r["n_gt_1e-3"] = int((d > 1e-3).sum())
     _RECORDS.append(r)
     # Regression alarms, NOT the contract (the callers assert that): 4-10x the largest values this report has ever held for the
-    # product build at full size (profiles/parity_r04.json: FSR float 2.3e-6, NIS float 8.9e-7, differing UNORM8 bytes 2.2e-5 of
+    # product build at full size (profiles/parity_r05.json: FSR float 2.3e-6, NIS float 8.9e-7, differing UNORM8 bytes 2.2e-5 of
     # an image) -- a change that spends more of the tolerance than that should be looked at before it is believed.
     if build == "product" and not config.startswith("C5"):   # (C5's float distance is its half rounding: 9.8e-4, asserted by the caller)
         if "max_abs" in r:
