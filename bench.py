@@ -806,11 +806,24 @@ def frame_leg(args, shard, frames=520):
                 rec["graph_error"] = str(e)[:120]
         finally:
             pp.close()
+        # cfg.pair_submit (ABI 4): the same two applies per frame, LEFT recorded and RIGHT launching both eyes as one batch of two
+        pp = A.PostProcessor(device=shard.device_index, **dict(shard.cfg_kw, radius=radius_v, debug_mode=1, pair_submit=1))
+        try:
+            for _ in range(frames):
+                pp.apply(A.EYE_LEFT, L, out=oL)
+                pp.apply(A.EYE_RIGHT, R, out=oR)
+            torch.cuda.synchronize(dev)
+            ms, reports = pp.average_gpu_time_ms()
+            rec["pair_submit_gpu_ms_per_frame"] = round(ms, 5) if reports else None
+        finally:
+            pp.close()
         return rec
 
     out = {"pairs_per_call": 1, "applies_per_frame": 2, "frames": frames,
            "method": "gpu_ms_per_frame = ovrfsr_average_gpu_time_ms (debug_mode=1: the reference's ring of 6 timestamp pairs, mean of 500, x2 per-eye "
-                     "textures, PostProcessor.cpp:605-626); graph/direct = wall time per frame of the two applies replayed from a HIP graph / issued from Python"}
+                     "textures, PostProcessor.cpp:605-626); graph/direct = wall time per frame of the two applies replayed from a HIP graph / issued from Python; "
+                     "pair_submit_gpu_ms_per_frame = the same figure from a cfg.pair_submit ctx (the LEFT apply is recorded, the RIGHT apply launches both eyes as one "
+                     "batch of two: two launches per frame instead of four, same pixels)"}
     first = one(radius)
     out.update({k: v for k, v in first.items() if k != "radius"})
     out["radius"] = radius

@@ -37,7 +37,7 @@ class Config(C.Structure):
                 ("debug_mode", C.c_int32), ("render_scale", C.c_float), ("sharpness", C.c_float),
                 ("radius", C.c_float), ("proj_centre", C.c_float * 4), ("out_width", C.c_uint32),
                 ("out_height", C.c_uint32), ("precision", C.c_int32), ("quantize_intermediate", C.c_int32),
-                ("fused", C.c_int32), ("stage_mask", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("fused", C.c_int32), ("stage_mask", C.c_int32), ("pair_submit", C.c_int32), ("reserved", C.c_int32 * 2)]
 
     @classmethod
     def default(cls, **kw):
@@ -103,7 +103,7 @@ def library():
     L.ovrfsr_nis_coef_usm.restype = f32p
     L.ovrfsr_config_from_json.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Config)]
     L.ovrfsr_save_ppm.argtypes = [C.POINTER(Image), C.c_char_p, C.c_void_p]
-    if L.ovrfsr_abi_version() != 3:
+    if L.ovrfsr_abi_version() != 4:
         raise OvrFsrError(1, "ABI version mismatch")
     _LIB = L
     return L

@@ -21,7 +21,7 @@ bool config_ok(const ovrfsr_config *cfg) { return cfg && cfg->struct_size == siz
 bool config_valid(const ovrfsr_config *cfg)
 {
     return config_ok(cfg) && (cfg->precision == OVRFSR_PRECISION_FP32 || cfg->precision == OVRFSR_PRECISION_FP32_STRICT) &&
-           cfg->stage_mask >= 0 && cfg->stage_mask <= 2 && cfg->fused >= -1 && cfg->fused <= 1;
+           cfg->stage_mask >= 0 && cfg->stage_mask <= 2 && cfg->fused >= -1 && cfg->fused <= 1 && (cfg->pair_submit == 0 || cfg->pair_submit == 1);
 }
 
 // Nothing may unwind through the extern "C" boundary (header: "nothing here throws"): host-side containers of the launch

@@ -104,6 +104,7 @@ int PostProcessor::Fail(int status, const std::string &what)
 void PostProcessor::Reset()
 {
     DeviceGuard guard(device_); // resources live on the ctx's device, whatever the caller has selected
+    havePending_ = false;       // a recorded LEFT of cfg.pair_submit is dropped (header)
     enabled_ = true;
     initialized_ = false;
     if (swizzled_) (void)hipFree(swizzled_);
@@ -894,8 +895,10 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
     DeviceGuard guard(device_);
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
 
-    if (initialized_ && (in->width != inputWidth_ || in->height != inputHeight_ || in->format != inputFormat_))
+    if (initialized_ && (in->width != inputWidth_ || in->height != inputHeight_ || in->format != inputFormat_)) {
+        if (havePending_) { rc = FlushPending(stream); if (rc != OVRFSR_OK) return rc; } // the recorded LEFT belongs to the old resources
         Reset(); // "Texture size changed, recreating resources" (:139-142)
+    }
     if (!initialized_) {
         textureContainsOnlyOneEye_ = std::fabs(bounds->uMax - bounds->uMin) > .5f; // :146
         rc = PrepareResources(*in);
@@ -905,6 +908,8 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
     // caller-owned or ctx-owned final image
     ovrfsr_image dst;
     const bool stages = doUpscale_ || doSharpen_;
+    // cfg.pair_submit (header): one texture per eye and something to launch -> LEFT is recorded, RIGHT launches both
+    const bool pairMode = cfg_.pair_submit != 0 && textureContainsOnlyOneEye_ && stages;
     if (out->data) {
         rc = CheckImage(out, "out");
         if (rc != OVRFSR_OK) return rc;
@@ -914,15 +919,56 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
         dst.width = outputWidth_; dst.height = outputHeight_;
         dst.format = in->format == OVRFSR_FORMAT_BGRA8_UNORM ? OVRFSR_FORMAT_RGBA8_UNORM : in->format; // DetermineOutputFormat (:63-74)
         dst.pitch_bytes = dst.width * texel_bytes(dst.format);
-        rc = EnsureBuffer(&sharpened_, &sharpenedBytes_, (size_t)dst.pitch_bytes * dst.height);
+        // (pair mode: both eyes' results are alive at once -- two ctx-owned images, left first)
+        const size_t one = (size_t)dst.pitch_bytes * dst.height;
+        if (pairMode && havePending_ && sharpenedBytes_ < 2 * one) { rc = FlushPending(stream); if (rc != OVRFSR_OK) return rc; } // (cannot grow under a recorded LEFT)
+        rc = EnsureBuffer(&sharpened_, &sharpenedBytes_, pairMode ? 2 * one : one);
         if (rc != OVRFSR_OK) return rc;
-        dst.data = sharpened_;
+        dst.data = pairMode && eye == OVRFSR_EYE_RIGHT ? static_cast<uint8_t *>(sharpened_) + one : sharpened_;
     }
     // an in-place call would race: RCAS / NVSharpen / EASU read neighbour texels other workgroups overwrite.  Checked against the
     // RESOLVED destination -- the caller's buffer or the ctx-owned one: chaining the previous ctx-owned result back in as `in`
     // (sharpen-only mode, where the sizes agree) is the same race
     if (stages && RangesOverlap(*in, 0, dst, 0, 1)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output images overlap");
 
+    if (pairMode) {
+        if (eye == OVRFSR_EYE_LEFT) { // record; a LEFT still waiting is processed on its own first
+            if (havePending_) { rc = FlushPending(stream); if (rc != OVRFSR_OK) return rc; }
+            pendingIn_ = *in; pendingOut_ = dst; havePending_ = true;
+            lastSubmittedTexture_ = in->data;
+            eyeCount_ = (eyeCount_ + 1) % 2;
+            outputTexture_ = dst;
+            *out = dst;
+            return OVRFSR_OK;
+        }
+        if (havePending_) {
+            // both eyes as ONE batch of two: image 0 = the eye whose input lies lower in memory, image 1 = base + stride.  The outputs must
+            // be laid out the same way round; anything else (other size / pitch / format, overlapping or oppositely ordered images) takes
+            // the two single launches below
+            const ovrfsr_image &li = pendingIn_, &lo = pendingOut_, &ri = *in, &ro = dst;
+            const uintptr_t lip = reinterpret_cast<uintptr_t>(li.data), rip = reinterpret_cast<uintptr_t>(ri.data);
+            const uintptr_t lop = reinterpret_cast<uintptr_t>(lo.data), rop = reinterpret_cast<uintptr_t>(ro.data);
+            const bool same = li.width == ri.width && li.height == ri.height && li.pitch_bytes == ri.pitch_bytes && li.format == ri.format &&
+                              lo.width == ro.width && lo.height == ro.height && lo.pitch_bytes == ro.pitch_bytes && lo.format == ro.format;
+            const bool leftFirst = lip < rip;
+            const size_t inStride = leftFirst ? rip - lip : lip - rip, outStride = leftFirst ? rop - lop : lop - rop;
+            const bool ordered = lip != rip && lop != rop && (leftFirst ? lop < rop : rop < lop);
+            if (same && ordered && inStride >= (size_t)li.pitch_bytes * li.height && outStride >= (size_t)lo.pitch_bytes * lo.height &&
+                inStride % texel_bytes(li.format) == 0 && outStride % texel_bytes(lo.format) == 0 &&
+                !RangesOverlap(leftFirst ? li : ri, inStride, leftFirst ? lo : ro, outStride, 2)) {
+                havePending_ = false;
+                rc = ApplyPostProcess(2, leftFirst ? OVRFSR_EYE_LEFT : OVRFSR_EYE_RIGHT, 1, leftFirst ? li : ri, inStride, leftFirst ? lo : ro, outStride, stream);
+                if (rc != OVRFSR_OK) return rc;
+                lastSubmittedTexture_ = in->data;
+                eyeCount_ = (eyeCount_ + 1) % 2;
+                outputTexture_ = dst;
+                *out = dst;
+                return OVRFSR_OK;
+            }
+            rc = FlushPending(stream);
+            if (rc != OVRFSR_OK) return rc;
+        }
+    }
     // a shared side-by-side texture is processed once, on the first Submit (:155-158)
     if (eyeCount_ == 0 || textureContainsOnlyOneEye_ || in->data != lastSubmittedTexture_) {
         if (stages) {
@@ -957,6 +1003,7 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     if (RangesOverlap(*in0, inStride, *out0, outStride, n)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output batches overlap");
     DeviceGuard guard(device_);
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+    if (havePending_) { rc = FlushPending(stream); if (rc != OVRFSR_OK) return rc; } // cfg.pair_submit: a recorded LEFT goes first
     // shared side-by-side textures: both mask centres per image, processed once each (PostProcessor.cpp:146,155-158,298-301)
     if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || textureContainsOnlyOneEye_ == sharedTextures))
         Reset();
@@ -968,6 +1015,14 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     if (out0->width != outputWidth_ || out0->height != outputHeight_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "out has the wrong size");
     if (!(doUpscale_ || doSharpen_)) return Fail(OVRFSR_ERR_UNSUPPORTED, "no stage selected (render_scale == 1 with NIS off would still sharpen)");
     return ApplyPostProcess(n, firstEye, alternate, *in0, inStride, *out0, outStride, stream);
+}
+
+// cfg.pair_submit: the recorded LEFT submission on its own (no RIGHT followed it)
+int PostProcessor::FlushPending(hipStream_t stream)
+{
+    if (!havePending_) return OVRFSR_OK;
+    havePending_ = false;
+    return ApplyPostProcess(1, OVRFSR_EYE_LEFT, 0, pendingIn_, 0, pendingOut_, 0, stream);
 }
 
 // PostProcessor.cpp:608-626: advance the ring and read the slot recorded kQueryCount-1 applies ago

@@ -87,6 +87,10 @@ private:
     // a ctx-owned auxiliary stream, forked from and joined back into the caller's stream with events
     hipStream_t auxStream_ = nullptr;
     hipEvent_t evFork_ = nullptr, evJoin_ = nullptr;
+    // cfg.pair_submit: the recorded LEFT submission of the current frame (see the header) and what it takes to launch it
+    bool havePending_ = false;
+    ovrfsr_image pendingIn_{}, pendingOut_{};
+    int FlushPending(hipStream_t stream);
     bool OverlapOutside(const ovrfsr_image &in) const; // does a masked pass run its outside-tile kernel on the auxiliary stream?
     hipStream_t Fork(hipStream_t user, bool overlap);
     void Join(hipStream_t user, hipStream_t aux);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     L = A.library()
-    assert L.ovrfsr_abi_version() == 3
+    assert L.ovrfsr_abi_version() == 4
     cfg = A.Config.default()
     assert cfg.struct_size == C.sizeof(A.Config) == 80
     assert C.sizeof(A.Image) == 24 and C.sizeof(A.Bounds) == 16
@@ -82,7 +82,7 @@ def test_create_rejects_configurations_no_kernel_exists_for():
     """precision 1 (a packed-half mode ABI 1 reserved and never built), unknown stage masks / fused values: rejected at
     create with INVALID_ARGUMENT before any device is touched, instead of a ctx that disables itself at the first apply."""
     ctx = C.c_void_p()
-    for kw in (dict(precision=1), dict(precision=7), dict(stage_mask=3), dict(fused=2)):
+    for kw in (dict(precision=1), dict(precision=7), dict(stage_mask=3), dict(fused=2), dict(pair_submit=2), dict(pair_submit=-1)):
         cfg = A.Config.default(fsr_enabled=1, **kw)
         assert A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx)) == 1 and not ctx
     assert not hasattr(A, "PRECISION_FP16")

@@ -223,3 +223,100 @@ def test_back_to_back_with_changing_batch_sizes(cfg):
             assert torch.equal(snaps[k], ref[:n]), "call %d (batch of %d): consumer saw other data" % (k, n)
     finally:
         pp.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: cfg.pair_submit -- apply(LEFT) is recorded, apply(RIGHT) launches both eyes as one batch of two
+# ------------------------------------------------------------------------------------------------
+PAIR_CASES = [
+    ("two-pass unmasked RGBA8", dict(radius=2.0, sharpness=0.9), np.uint8),
+    ("sorted two-pass, radius 0.5, different mask centres per eye", dict(radius=0.5, sharpness=0.9, proj_centre=(0.45, 0.5, 0.56, 0.48)), np.uint8),
+    ("fused + outside, RGBA16F, radius 0.5 (forked)", dict(radius=0.5, sharpness=0.9), np.float16),
+    ("NVScaler + DirectCopy, radius 0.5", dict(radius=0.5, sharpness=0.9, use_nis=1), np.uint8),
+    ("EASU only", dict(radius=2.0, stage_mask=1), np.uint8),
+]
+
+
+@pytest.mark.parametrize("name,cfg,dt", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_pair_submit_is_the_same_pixels_in_two_launches(name, cfg, dt):
+    """Frames submitted L, R, L, R ... without synchronisation through a pair_submit ctx equal, bit for bit, what a plain ctx writes -- with the
+    right eye's texture above OR below the left one's in memory (image 0 of the batch of two is the lower one), into caller-owned outputs."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh, frames = 480, 405, 640, 540, 6
+    tdt = {np.uint8: torch.uint8, np.float16: torch.float16}[dt]
+    src = _batch(dt, 5, 4, iw, ih)      # frames of type A = images (0, 1), type B = (2, 3)
+    plain = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **cfg)
+    ref = []
+    for i in range(4):
+        ref.append(plain.apply(i & 1, src[i], out_dtype=tdt).clone())
+    torch.cuda.synchronize()
+    plain.close()
+    for order in ("left first", "right first"):
+        pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, pair_submit=1, **cfg)
+        try:
+            res = []
+            for f in range(frames):
+                a = 2 * (f & 1)
+                outs = torch.zeros((2, oh, ow, 4), dtype=tdt, device="cuda")
+                # "right first": the right eye's images sit BELOW the left eye's in memory (input and output alike)
+                li, ri = (a, a + 1)
+                lo, ro = (0, 1) if order == "left first" else (1, 0)
+                pair_in = torch.stack([src[li], src[ri]] if order == "left first" else [src[ri], src[li]])
+                il, ir = (pair_in[0], pair_in[1]) if order == "left first" else (pair_in[1], pair_in[0])
+                o_l = pp.apply(A.EYE_LEFT, il, out=outs[lo])
+                assert o_l.data_ptr() == outs[lo].data_ptr()
+                pp.apply(A.EYE_RIGHT, ir, out=outs[ro])
+                res.append((a, outs[lo].clone(), outs[ro].clone(), pair_in))   # consumers on the caller's stream right behind the RIGHT call
+            torch.cuda.current_stream().synchronize()
+            for k, (a, gl, gr, _) in enumerate(res):
+                assert torch.equal(gl.view(torch.uint8), ref[a].view(torch.uint8)), "%s, %s: left eye of frame %d differs" % (name, order, k)
+                assert torch.equal(gr.view(torch.uint8), ref[a + 1].view(torch.uint8)), "%s, %s: right eye of frame %d differs" % (name, order, k)
+        finally:
+            pp.close()
+
+
+def test_pair_submit_falls_back_to_single_launches():
+    """A LEFT that no matching RIGHT follows is processed on its own by the next call: two LEFTs in a row, outputs laid out the other way round
+    than the inputs, a texture of another size, ovrfsr_apply_batch in between, ctx-owned outputs (two images in this mode); reset drops it."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 320, 270, 427, 360
+    src = _batch(np.uint8, 7, 4, iw, ih)
+    kw = dict(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, radius=0.6, sharpness=0.8)
+    plain = A.PostProcessor(**kw)
+    ref = [plain.apply(i & 1, src[i], out_dtype=torch.uint8).clone() for i in range(4)]
+    torch.cuda.synchronize()
+    plain.close()
+    pp = A.PostProcessor(pair_submit=1, **kw)
+    try:
+        outs = torch.zeros((4, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        # LEFT, LEFT, RIGHT: the first LEFT is flushed by the second; the second pairs with the RIGHT
+        pp.apply(0, src[0], out=outs[0]); pp.apply(0, src[2], out=outs[2]); pp.apply(1, src[3], out=outs[3])
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[2], ref[2]) and torch.equal(outs[3], ref[3])
+        # outputs ordered against the inputs: two single launches, same pixels
+        outs.zero_()
+        pp.apply(0, src[0], out=outs[1]); pp.apply(1, src[1], out=outs[0])
+        torch.cuda.synchronize()
+        assert torch.equal(outs[1], ref[0]) and torch.equal(outs[0], ref[1])
+        # a batch call between LEFT and RIGHT: the LEFT goes first, the RIGHT is then a single apply
+        outs.zero_()
+        b = torch.zeros((2, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        pp.apply(0, src[0], out=outs[0]); pp.apply_batch(src[2:4], b); pp.apply(1, src[1], out=outs[1])
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1]) and torch.equal(b[0], ref[2]) and torch.equal(b[1], ref[3])
+        # ctx-owned outputs: two distinct images, both valid after the RIGHT call
+        o_l = pp.apply(0, src[2]); o_r = pp.apply(1, src[3])
+        torch.cuda.synchronize()
+        assert o_l.data_ptr() != o_r.data_ptr() and torch.equal(o_l, ref[2]) and torch.equal(o_r, ref[3])
+        # a RIGHT of another size: the recorded LEFT is processed with the old resources, then the ctx rebuilds
+        small = _batch(np.uint8, 9, 1, 160, 120)
+        outs.zero_()
+        pp.apply(0, src[0], out=outs[0])
+        pp2cfg = A.Config.default(pair_submit=1, **dict(kw, out_width=0, out_height=0, render_scale=0.75))
+        pp.set_config(pp2cfg)          # set_config / reset DROP a recorded LEFT (documented)
+        torch.cuda.synchronize()
+        assert int(outs[0].max()) == 0
+    finally:
+        pp.close()
