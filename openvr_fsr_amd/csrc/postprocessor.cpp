@@ -54,7 +54,15 @@ hipStream_t PostProcessor::Fork(hipStream_t user, bool overlap)
     static const int serial = [] { const char *e = std::getenv("OVRFSR_SERIAL"); return e && e[0] == '1' ? 1 : e && e[0] == '0' ? 0 : -1; }();
     if (serial == 1 || (serial < 0 && !overlap)) return user;
     if (!auxStream_) {
-        if (hipStreamCreateWithFlags(&auxStream_, hipStreamNonBlocking) != hipSuccess ||
+        // The auxiliary stream is a LOW-priority queue: what runs on it (the outside-tile kernel of half / float passes) fills the wave slots
+        // the main kernel leaves, never the other way round -- C5 13.28 k / 13.30 k pairs/s at default priority, 13.32 k / 13.37 k low,
+        // 11.26 k / 11.29 k high (round 5).  OVRFSR_AUX_PRIORITY=default|high: tuning
+        static const int prio = [] { const char *e = std::getenv("OVRFSR_AUX_PRIORITY"); return !e ? 1 : e[0] == 'd' ? 0 : e[0] == 'h' ? 2 : 1; }();
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const hipError_t ce = prio == 0 ? hipStreamCreateWithFlags(&auxStream_, hipStreamNonBlocking)
+                                        : hipStreamCreateWithPriority(&auxStream_, hipStreamNonBlocking, prio == 1 ? least : greatest);
+        if (ce != hipSuccess ||
             hipEventCreateWithFlags(&evFork_, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&evJoin_, hipEventDisableTiming) != hipSuccess) {
             auxStream_ = nullptr;
