@@ -261,6 +261,10 @@ OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_conf
 
 /* Stand-in for the F7 capture (PostProcessor.cpp:640-657): dump a device image as a binary PPM. */
 OVRFSR_API int ovrfsr_save_ppm(const ovrfsr_image *img, const char *path, void *stream);
+/* The capture in the reference's own container: a DDS file (SaveDDSTextureToFile, PostProcessor.cpp:652; DX10 header extension, one mip)
+ * holding the texels exactly as they sit in the image -- R8G8B8A8_UNORM, R16G16B16A16_FLOAT, R32G32B32A32_FLOAT, R10G10B10A2_UNORM or
+ * B8G8R8A8_UNORM --, rows tightly packed.  (ABI 4) */
+OVRFSR_API int ovrfsr_save_dds(const ovrfsr_image *img, const char *path, void *stream);
 
 OVRFSR_API uint32_t ovrfsr_abi_version(void);
 

@@ -174,4 +174,44 @@ static int save_ppm_impl(const ovrfsr_image *img, const char *path, void *stream
     return OVRFSR_OK;
 }
 
+// The F7 capture itself writes a DDS (SaveDDSTextureToFile, PostProcessor.cpp:640-657 / ScreenGrab11.h): a DDS file with the DX10 header
+// extension, one mip, the texels exactly as they sit in the image (no conversion: what a capture is for) -- "DDS " + DDS_HEADER (124 bytes:
+// caps, height, width, pitch, pixel format FourCC 'DX10') + DDS_HEADER_DXT10 (DXGI format, TEXTURE2D, array size 1) + tightly packed rows.
+static int save_dds_impl(const ovrfsr_image *img, const char *path, void *stream)
+{
+    if (!img || !img->data || !path || img->format > OVRFSR_FORMAT_BGRA8_UNORM || img->width == 0 || img->height == 0) return OVRFSR_ERR_INVALID_ARGUMENT;
+    // DXGI_FORMAT_R8G8B8A8_UNORM = 28, R16G16B16A16_FLOAT = 10, R32G32B32A32_FLOAT = 2, R10G10B10A2_UNORM = 24, B8G8R8A8_UNORM = 87
+    static const uint32_t dxgi[5] = {28u, 10u, 2u, 24u, 87u}, bytes[5] = {4u, 8u, 16u, 4u, 4u};
+    const uint32_t tb = bytes[img->format], rowBytes = img->width * tb;
+    std::vector<unsigned char> host((size_t)img->pitch_bytes * img->height);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(host.data(), img->data, host.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return OVRFSR_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return OVRFSR_ERR_HIP;
+    uint32_t h[32] = {0};                       // "DDS " + 31 dwords of DDS_HEADER
+    h[0] = 0x20534444u;                         // magic
+    h[1] = 124u;                                // dwSize
+    h[2] = 0x1u | 0x2u | 0x4u | 0x8u | 0x1000u; // DDSD_CAPS | HEIGHT | WIDTH | PITCH | PIXELFORMAT
+    h[3] = img->height; h[4] = img->width; h[5] = rowBytes;
+    h[7] = 1u;                                  // dwMipMapCount
+    h[19] = 32u;                                // DDS_PIXELFORMAT.dwSize
+    h[20] = 0x4u;                               // DDPF_FOURCC
+    h[21] = 0x30315844u;                        // 'DX10'
+    h[27] = 0x1000u;                            // DDSCAPS_TEXTURE
+    const uint32_t dx10[5] = {dxgi[img->format], 3u /* D3D10_RESOURCE_DIMENSION_TEXTURE2D */, 0u, 1u /* arraySize */, 0u};
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return OVRFSR_ERR_INVALID_ARGUMENT;
+    bool ok = std::fwrite(h, 4, 32, f) == 32 && std::fwrite(dx10, 4, 5, f) == 5;
+    for (uint32_t y = 0; ok && y < img->height; ++y) ok = std::fwrite(host.data() + (size_t)y * img->pitch_bytes, 1, rowBytes, f) == rowBytes;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? OVRFSR_OK : OVRFSR_ERR_INVALID_ARGUMENT;
+}
+OVRFSR_API int ovrfsr_save_dds(const ovrfsr_image *img, const char *path, void *stream)
+{
+    try {
+        return save_dds_impl(img, path, stream);
+    } catch (...) {
+        return OVRFSR_ERR_OUT_OF_MEMORY;
+    }
+}
+
 } // extern "C"

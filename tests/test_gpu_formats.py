@@ -245,3 +245,32 @@ def test_half_intermediate_is_the_strict_builds_also_on_hdr(gpu, scale, kind, mo
         assert not (differ & guarded).any(), "%d guarded half stores differ from the strict build (scale %g, %s)" % (int((differ & guarded).sum()), scale, kind)
         ulp = np.maximum(np.abs(s32), 2.0 ** -14) * 2.0 ** -10        # one half spacing (upper bound inside the binade)
         assert (np.abs(s32 - p32)[differ] <= ulp[differ] * 1.0001).all()
+
+
+@pytest.mark.parametrize("dt", [np.uint8, np.float16, np.float32])
+def test_capture_dds(gpu, tmp_path, dt):
+    """ovrfsr_save_dds: the F7 capture in the reference's own container (SaveDDSTextureToFile, PostProcessor.cpp:640-657) -- DX10-extended
+    DDS, the texels as they sit in the image (row pitch removed), parsed back here field by field."""
+    import ctypes as C
+    import struct
+    import torch
+    import openvr_fsr_amd as A
+    from openvr_fsr_amd.postprocessor import image_of
+    ow, oh, pad = 77, 45, 5
+    tdt = {np.uint8: torch.uint8, np.float16: torch.float16, np.float32: torch.float32}[dt]
+    big = (torch.rand((oh, ow + pad, 4), device="cuda") * (255 if dt == np.uint8 else 3.0)).to(tdt)   # a view with a row pitch wider than the image
+    view = big[:, :ow]
+    path = str(tmp_path / "cap.dds")
+    assert A.library().ovrfsr_save_dds(C.byref(image_of(view)), path.encode(), None) == 0
+    data = open(path, "rb").read()
+    tb = np.dtype(dt).itemsize * 4
+    assert len(data) == 4 + 124 + 20 + ow * oh * tb
+    magic, size, flags, height, width, pitch = struct.unpack_from("<6I", data, 0)
+    assert magic == 0x20534444 and size == 124 and flags == 0x100f and (height, width, pitch) == (oh, ow, ow * tb)
+    pf_size, pf_flags, fourcc = struct.unpack_from("<3I", data, 4 + 72)
+    assert pf_size == 32 and pf_flags == 4 and fourcc == struct.unpack("<I", b"DX10")[0]
+    dxgi, dim, misc, array, misc2 = struct.unpack_from("<5I", data, 128)
+    assert dxgi == {np.uint8: 28, np.float16: 10, np.float32: 2}[dt] and dim == 3 and array == 1
+    px = np.frombuffer(data[148:], dt).reshape(oh, ow, 4)
+    assert np.array_equal(px.view(np.uint8), view.contiguous().cpu().numpy().view(np.uint8))
+    assert A.library().ovrfsr_save_dds(None, path.encode(), None) == 1
