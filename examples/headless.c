@@ -5,7 +5,10 @@
  *   gcc -std=c11 -O2 -D__HIP_PLATFORM_AMD__ examples/headless.c -Iinclude -I/opt/rocm/include -Lopenvr_fsr_amd -lopenvr_fsr_amd \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,'$ORIGIN/../openvr_fsr_amd' -Wl,-rpath,/opt/rocm/lib -o examples/headless
  *   (plain gcc: the only HIP the caller needs is hipMalloc/hipMemcpy for its own buffers; __graft_entry__.build() does this)
- *   examples/headless [openvr_mod.cfg] [out.ppm]
+ *   examples/headless [openvr_mod.cfg | -] [out.ppm | out.dds] [--pair]
+ * A capture path ending in .dds is written with ovrfsr_save_dds (the reference's F7 container), anything else as a PPM.  --pair runs the same
+ * frames through cfg.pair_submit: the LEFT apply only records, the RIGHT apply launches both eyes as one batch of two -- the
+ * left eye's ctx-owned image is complete once the RIGHT call has returned, and the two eyes must produce the same checksum as without it.
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -32,6 +35,9 @@ int main(int argc, char **argv)
         cfg.debug_mode = 1; /* for ovrfsr_last_gpu_time_ms */
     }
     cfg.out_width = 2244; cfg.out_height = 2492;
+    int pair = 0;
+    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--pair")) pair = 1;
+    cfg.pair_submit = pair;
 
     uint8_t *h = (uint8_t *)malloc((size_t)inW * inH * 4);
     for (uint32_t y = 0; y < inH; ++y)
@@ -59,8 +65,19 @@ int main(int argc, char **argv)
             if (ovrfsr_last_gpu_time_ms(ctx, &ms) == OVRFSR_OK)
                 printf("eye %d: %ux%u -> %ux%u  %s  %.3f ms on the GPU\n", eye, inW, inH, out.width, out.height,
                        cfg.use_nis ? "NIS" : "EASU+RCAS", ms);
-            if (rep == 2 && eye == 1 && argc > 2) {
-                rc = ovrfsr_save_ppm(&out, argv[2], NULL);
+            if (rep == 2 && eye == 1) { /* a checksum of the right eye's result: the same with and without --pair */
+                const size_t nb = (size_t)out.pitch_bytes * out.height;
+                uint8_t *o = (uint8_t *)malloc(nb);
+                CHECK_HIP(hipMemcpy(o, out.data, nb, hipMemcpyDeviceToHost));
+                uint64_t hsh = 0xcbf29ce484222325ull;
+                for (size_t k = 0; k < nb; ++k) { hsh ^= o[k]; hsh *= 0x100000001b3ull; }
+                free(o);
+                printf("right eye checksum %016llx%s\n", (unsigned long long)hsh, pair ? " (pair_submit)" : "");
+            }
+            if (rep == 2 && eye == 1 && argc > 2 && strcmp(argv[2], "--pair") != 0) {
+                const size_t L = strlen(argv[2]);
+                const int dds = L > 4 && !strcmp(argv[2] + L - 4, ".dds");
+                rc = dds ? ovrfsr_save_dds(&out, argv[2], NULL) : ovrfsr_save_ppm(&out, argv[2], NULL);
                 printf("%s %s\n", rc == OVRFSR_OK ? "wrote" : "could not write", argv[2]);
             }
         }

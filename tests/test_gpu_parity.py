@@ -673,6 +673,15 @@ def test_plain_c_caller(gpu, tmp_path):
     assert data.startswith(b"P6\n2244 2492\n255\n") and len(data) == len(b"P6\n2244 2492\n255\n") + 2244 * 2492 * 3
     px = np.frombuffer(data[len(b"P6\n2244 2492\n255\n"):], np.uint8)
     assert px.std() > 10    # an image, not a constant
+    # round 5 from plain C: cfg.pair_submit (LEFT recorded, RIGHT launches both eyes) gives the same right eye, and the DDS capture
+    dds = str(tmp_path / "eye.dds")
+    r2 = subprocess.run([exe, "-", dds, "--pair"], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0, r2.stderr
+    cs = [l.split()[3] for l in r.stdout.splitlines() if l.startswith("right eye checksum")]
+    cs2 = [l.split()[3] for l in r2.stdout.splitlines() if l.startswith("right eye checksum")]
+    assert len(cs) == 1 and cs == cs2 and "(pair_submit)" in r2.stdout
+    d = open(dds, "rb").read()
+    assert d[:4] == b"DDS " and len(d) == 148 + 2244 * 2492 * 4 and np.array_equal(np.frombuffer(d[148:], np.uint8).reshape(2492, 2244, 4)[..., :3].reshape(-1), px)
 
 
 def test_c_node_driver(gpu):
