@@ -41,6 +41,7 @@ PATCHED = [
     ("soa", "-DOVRFSR_EASU_SOA", "easu_soa"),
     ("fsb", "-DOVRFSR_EASU_FS_BUNDLE -DOVRFSR_EASU_OCC5", "easu_fs_bundle"),
     ("mme", "-DOVRFSR_EASU_MM_EARLY", "easu_fs_bundle"),
+    ("rpipe", "-DOVRFSR_RCAS_PIPE", "rcas_pipe"),
 ]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
