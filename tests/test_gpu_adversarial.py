@@ -87,7 +87,7 @@ def test_audit_build_finds_no_flip():
     also built by __graft_entry__.build()) re-resolves EVERY pixel of the product EASU in the reference's operator order inside the same kernels
     and counts, on the device, the pixels the guard did NOT list whose stored UNORM8 bytes / guarded halves differ from the strict build's.  A
     reduced campaign of tools/debug/tie_audit.py (every configuration, structured / random / extremes / adversarial-mosaic content, half
-    pipelines at x1 / x6 / x40) must report flips == 0; the full campaign (2.2e9 pixels) and the adversarial search under the audit build are
+    pipelines at x1 / x6 / x40) must report flips == 0; the full campaigns (8.9e9 pixels) and the adversarial search under the audit build are
     recorded in profiles/r05_tie_audit.txt."""
     import re
     import subprocess
