@@ -42,7 +42,7 @@ PATCHED = [
     ("fsb", "-DOVRFSR_EASU_FS_BUNDLE -DOVRFSR_EASU_OCC5", "easu_fs_bundle"),
     ("mme", "-DOVRFSR_EASU_MM_EARLY", "easu_fs_bundle"),
     ("rpipe", "-DOVRFSR_RCAS_PIPE", "rcas_pipe"),
-    ("px2", "-DOVRFSR_RCAS_PX2 -DOVRFSR_RCAS_PX2_OCC=", "rcas_px2"),
+    ("px2", "-DOVRFSR_RCAS_PX2", "rcas_px2"),
 ]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

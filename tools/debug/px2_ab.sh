@@ -1,18 +1,8 @@
 #!/bin/bash
-export OVRFSR_LIB=$PWD/ab/px2.so
+# tools/debug/px2_ab.sh -- A/B of tools/variants/rcas_px2.patch (profiles/r05_sched_ab.txt section 7): PX2_LIB=ab/px2.so, built by
+#   PATCHES=rcas_px2 tools/variants/build.sh px2 "-DOVRFSR_RCAS_PX2"; one library, the form chosen per process by OVRFSR_RCAS_PX2=0|16|32
+export OVRFSR_LIB=$PWD/${PX2_LIB:-ab/px2.so}
 run() { python bench.py --no-cpu --no-extras --pmc off --steps 20 --warmup 5 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('pairs/s', d['value'], 'dominant_ms', r['launch_ms'], 'parity', (d.get('parity_check') or {}).get('ok'))"; }
-python - <<'PY'
-import os, torch, numpy as np
-import openvr_fsr_amd as A, bench
-dev = torch.device("cuda")
-for (w,h) in ((2244,2492),(1000,777),(124,40),(125,33),(63,17)):
-    x = bench.random_batch(2, w, h, torch.uint8, dev, 7)
-    outs = []
-    for v in ("0","16","32"):
-        os.environ["OVRFSR_RCAS_PX2"] = v
-        # env is latched per process in a static: run each in a subprocess instead
-    print("size", w, h)
-PY
 for v in 0 16 32; do
 OVRFSR_RCAS_PX2=$v python - <<'PY'
 import os, torch, hashlib

@@ -11,7 +11,7 @@
 #   tools/variants/build.sh narrow   "-DOVRFSR_FUSED_NARROW=1"     profiles/r04_fused_variants.txt (5)
 #   tools/variants/build.sh compact  "-DOVRFSR_NIS_COMPACT"        profiles/r04_nis_compaction.txt   ([-DOVRFSR_NIS_DENSE_LANES=N])
 #   PATCHES=easu_fs_bundle tools/variants/build.sh fsb "-DOVRFSR_EASU_FS_BUNDLE [-DOVRFSR_EASU_OCC5]" | mme "-DOVRFSR_EASU_MM_EARLY"   profiles/r05_sched_ab.txt
-#   PATCHES=rcas_px2 tools/variants/build.sh px2 "-DOVRFSR_RCAS_PX2 -DOVRFSR_RCAS_PX2_OCC="  (run with OVRFSR_RCAS_PX2=32|16)   profiles/r05_sched_ab.txt (7)
+#   PATCHES=rcas_px2 tools/variants/build.sh px2 "-DOVRFSR_RCAS_PX2 [-DOVRFSR_RCAS_PX2_WAVES=N]"  (run with OVRFSR_RCAS_PX2=32|16)   profiles/r05_sched_ab.txt (7)
 #   tools/variants/build.sh nishalf  "-DOVRFSR_NIS_HALF_LDS"       profiles/r03_nis_variants.txt
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
