@@ -717,6 +717,34 @@ def test_c_node_driver(gpu):
     assert json.loads(r.stdout.strip().splitlines()[-1])["value"] > 0
 
 
+@pytest.mark.parametrize("launcher", ["direct", "torchrun"])
+def test_driver_commands_on_real_shards(gpu, launcher):
+    """The round driver's N > 1 commands -- `python bench.py --gpus 2 ...` and the same under `python -m torch.distributed.run --nproc-per-node 2` --
+    on REAL shards (tests/test_bench_launcher.py runs them on mock shards on CPU): gpurun boxes have one GPU, so both shards sit on device 0
+    (--oversubscribe; the line says so).  One JSON line, one per-device time and one parity record per shard (image 0 of each shard's own timed
+    batch against the oracle, gathered over the ranks), value = 2 x pairs x steps / the slowest shard."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = ["bench.py", "--gpus", "2", "--oversubscribe", "--pairs", "4", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-extras", "--pmc", "off"]
+    cmd = [sys.executable] + tail if launcher == "direct" else \
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533"] + tail
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and "oversubscribed" in d["config"]
+    per_dev = d["config"]["per_device_ms_per_step"]
+    assert len(per_dev) == 2 and all(m > 0 for m in per_dev) and d["ms_per_step"] >= max(per_dev) * 0.95
+    assert d["value"] == pytest.approx(2 * 4 / (d["ms_per_step"] * 1e-3), rel=1e-3)
+    pc = d["parity_check"]
+    assert pc["ok"] is True and pc["failed_shards"] == [] and [p["shard"] for p in pc["per_shard"]] == [0, 1] and all(p["ok"] for p in pc["per_shard"])
+    assert ("one rank per GPU" in d["config"]["launcher"]) == (launcher == "torchrun"), d["config"]["launcher"]
+
+
 # ------------------------------------------------------------------------------------------------
 # round 2: the reference's averaged GPU-time log, and the two product RCAS kernels agree byte for byte
 # ------------------------------------------------------------------------------------------------
