@@ -43,6 +43,7 @@ PATCHED = [
     ("mme", "-DOVRFSR_EASU_MM_EARLY", "easu_fs_bundle"),
     ("rpipe", "-DOVRFSR_RCAS_PIPE", "rcas_pipe"),
     ("px2", "-DOVRFSR_RCAS_PX2", "rcas_px2"),
+    ("rlds", "", "rcas_lds_cap"),
 ]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
