@@ -28,7 +28,7 @@ extern "C" {
 #define OVRFSR_API
 #endif
 
-#define OVRFSR_ABI_VERSION 4u /* 4: ovrfsr_config::pair_submit (was reserved[0]; same struct size).  3: ovrfsr_apply_batch_shared added.  2: ovrfsr_average_gpu_time_ms added; precision value 1 (never built) removed */
+#define OVRFSR_ABI_VERSION 5u /* 5: ovrfsr_pair_pending added; pair_submit pairs by arrival order; create / set_config validate the float fields.  4: ovrfsr_config::pair_submit (was reserved[0]; same struct size).  3: ovrfsr_apply_batch_shared added.  2: ovrfsr_average_gpu_time_ms added; precision value 1 (never built) removed */
 
 typedef enum ovrfsr_status {
     OVRFSR_OK = 0,
@@ -108,7 +108,19 @@ typedef struct ovrfsr_bounds { float uMin, vMin, uMax, vMax; } ovrfsr_bounds;
 
 /* The numeric fields of the reference's Config singleton that reach the GPU
  * (src/postprocess/Config.h:10-17), plus the values the reference obtains from the OpenVR runtime
- * (projection centres, PostProcessor.cpp:104-121) and implementation knobs of this library. */
+ * (projection centres, PostProcessor.cpp:104-121) and implementation knobs of this library.
+ *
+ * Configuration values.  The mask centre and radius are float expressions converted to uint32 (PostProcessor.cpp:298-305); the
+ * reference validates nothing -- its one rule is `if (sharpness < 0) sharpness = 0` (Config.h:40) -- and that conversion is undefined
+ * behaviour in C++ for NaN, negative or huge values.  This library never evaluates it on such a value:
+ *   - ovrfsr_create / ovrfsr_set_config return OVRFSR_ERR_INVALID_ARGUMENT (no ctx is built / the old cfg stays) for a radius that is
+ *     not finite or is negative, a sharpness or render_scale that is not finite, or a proj_centre component outside [-1, 2] (or NaN);
+ *   - sharpness is otherwise clamped to [0, 1] where the reference clamps it (PostProcessor.cpp:420, NIS_Config.h);
+ *   - ovrfsr_mask_constants is total: for 0 <= x < 2^32 the conversion is the reference's truncation (every known answer holds), NaN
+ *     and negative values give 0, values >= 2^32 give 0xffffffff (the saturating float->uint of the shader model that reads the
+ *     cbuffer); radius^2 keeps the reference's uint32 wrap-around (radius * outH / 2 >= 65536: defined, if useless, there too);
+ *   - ovrfsr_config_from_json clamps a negative radius to 0 exactly as the reference clamps a negative sharpness, and treats a
+ *     number that overflows float as "Could not read config file" (defaults, OVRFSR_ERR_INVALID_ARGUMENT). */
 typedef struct ovrfsr_config {
     uint32_t struct_size;    /* = sizeof(ovrfsr_config); ABI guard                               */
     int32_t fsr_enabled;     /* Config::fsrEnabled: 0 -> apply() is a pass-through (output = input
@@ -124,9 +136,9 @@ typedef struct ovrfsr_config {
     float render_scale;      /* Config::renderScale; <1: out = in / scale, >=1: out = in * scale,
                                 both truncated to uint (PostProcessor.cpp:512-518)               */
     float sharpness;         /* Config::sharpness, [0,1] (clamped where the reference clamps)    */
-    float radius;            /* Config::radius, in units of outH/2; 2.0 disables the mask        */
+    float radius;            /* Config::radius, in units of outH/2; 2.0 disables the mask; finite, >= 0 */
     float proj_centre[4];    /* {Lx, Ly, Rx, Ry} in [0,1]: what CalculateProjectionCenter()
-                                returned for each eye; default 0.5                               */
+                                returned for each eye; default 0.5; accepted range [-1, 2]       */
     uint32_t out_width;      /* explicit output size; 0,0 = derive from render_scale             */
     uint32_t out_height;
     int32_t precision;       /* ovrfsr_precision                                                 */
@@ -145,17 +157,26 @@ typedef struct ovrfsr_config {
                                 stage only (BASELINE config C1 "EASU-only"), 2 = sharpen stage only  */
     int32_t pair_submit;     /* 0 = every ovrfsr_apply processes its eye at once: the reference's pattern, two dispatches per Submit,
                                 four dependent launches per frame (PostProcessor.cpp:586-594).
-                                1 = deferred pair, for submissions with one texture per eye: ovrfsr_apply(LEFT) only RECORDS the
-                                submission and returns, in *out, the image the left eye's result will be written to;
-                                ovrfsr_apply(RIGHT) then launches BOTH eyes as one batch of two -- two launches per frame.  The left
-                                output is complete, in stream order, once the RIGHT call has returned: a host must hold back whatever
-                                consumes the left eye (the forwarded Submit) until then.  Same pixels, bit for bit.
+                                1 = deferred pair, for submissions with one texture per eye: the ovrfsr_apply of the FIRST eye of a frame
+                                -- LEFT or RIGHT, games submit in either order -- only RECORDS the submission and returns, in *out, the
+                                image that eye's result will be written to (ovrfsr_pair_pending() then returns 1); the ovrfsr_apply of
+                                the OTHER eye then launches BOTH as one batch of two -- two launches per frame.  The first eye's output is complete, in stream order, once the
+                                second call has returned: a host must hold back whatever consumes it (the forwarded Submit,
+                                INTEGRATION.md) until then, and the first eye's INPUT texture must stay unmodified until then too (it is
+                                read when the pair is launched, not when it is recorded).  Same pixels, bit for bit.
                                 One frame costs 0.097 instead of 0.110 ms of GPU time at 1683x1869 -> 2244x2492 (ramp-up, the partly
                                 filled last round of workgroups and the drain are paid per launch), 0.05 instead of 0.07 ms at the
-                                shipped radius 0.5.  A LEFT that no RIGHT follows -- another LEFT, a texture of another size or format,
-                                output images not laid out like the inputs, ovrfsr_apply_batch* -- is processed on its own by that next
-                                call; ovrfsr_reset / ovrfsr_set_config / ovrfsr_destroy DROP a recorded LEFT.  Both eyes must then get
-                                their own output image: caller-owned ones, or the two ctx-owned images of this mode                */
+                                shipped radius 0.5.  The two images of a pair may sit anywhere in memory relative to each other (inputs
+                                and outputs independently).  A recorded eye whose other eye does not follow -- the same eye again, a
+                                texture of another size or format, one texture submitted for both eyes, outputs that overlap,
+                                ovrfsr_apply_batch* -- is processed on its own by that next call.  A disturbed sequence does not become
+                                a standing lag: after the same eye twice in a row nothing is recorded until the other eye is seen again
+                                (a host that submits ONE eye per frame pays one late result, once), and a frame's second eye that finds
+                                nothing recorded (its partner went out with a batch call or a size change) is processed at once; only a
+                                host that REVERSES its eye order mid-stream should call ovrfsr_reset.  ovrfsr_reset /
+                                ovrfsr_set_config / ovrfsr_destroy DROP a recorded eye and forget the learned order.  Both eyes must get their own output image:
+                                caller-owned ones, or the two ctx-owned images of this mode (a ctx-owned image handed out for a recorded
+                                eye stays valid across the rebuild a size change triggers, until the next reset)                */
     int32_t reserved[2];
 } ovrfsr_config;
 
@@ -231,6 +252,12 @@ OVRFSR_API int ovrfsr_last_gpu_time_ms(ovrfsr_ctx *ctx, float *ms);
  * first), *reports = how many have been published; with OVRFSR_LOG=1 in the environment each one is also printed to
  * stderr in the reference's wording.  Only recorded when cfg.debug_mode != 0. */
 OVRFSR_API int ovrfsr_average_gpu_time_ms(ovrfsr_ctx *ctx, float *ms, uint32_t *reports);
+
+/* cfg.pair_submit (ABI 5): 1 when the most recent ovrfsr_apply on this ctx only RECORDED its submission (nothing was launched for it; its
+ * output image will be complete once the next ovrfsr_apply has returned), 0 otherwise (also for a NULL ctx and with pair_submit off).
+ * What a Submit detour needs to decide whether to hold the forwarded Submit back.  The reference has no counterpart:
+ * it processes every eye inside its own Submit (VrHooks.cpp:50-62). */
+OVRFSR_API int ovrfsr_pair_pending(const ovrfsr_ctx *ctx);
 
 /* ---- constants-only entry points (known-answer tests; no GPU needed) ------------------------- */
 

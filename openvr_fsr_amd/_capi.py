@@ -104,7 +104,8 @@ def library():
     L.ovrfsr_config_from_json.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(Config)]
     L.ovrfsr_save_ppm.argtypes = [C.POINTER(Image), C.c_char_p, C.c_void_p]
     L.ovrfsr_save_dds.argtypes = [C.POINTER(Image), C.c_char_p, C.c_void_p]
-    if L.ovrfsr_abi_version() != 4:
+    L.ovrfsr_pair_pending.argtypes = [C.c_void_p]
+    if L.ovrfsr_abi_version() != 5:
         raise OvrFsrError(1, "ABI version mismatch")
     _LIB = L
     return L

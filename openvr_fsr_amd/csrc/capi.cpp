@@ -8,6 +8,7 @@
 #include <new>
 #include "postprocessor.hpp"
 #include "fsr_launch.h"
+#include "fsr_bounds.h"
 #include "nis_tables.h"
 
 struct ovrfsr_ctx {
@@ -18,10 +19,22 @@ namespace {
 bool config_ok(const ovrfsr_config *cfg) { return cfg && cfg->struct_size == sizeof(ovrfsr_config); }
 // what create / set_config accept: a ctx is never built around a configuration no kernel exists for (and so never
 // disables itself over one at the first apply)
+// The float fields feed float -> uint32 conversions (mask centre and radius, PostProcessor.cpp:298-305) and clamps: a ctx is only ever built
+// around values for which every one of them is defined (header, "Configuration values").  The reference validates none of this -- its only
+// rule is `if (sharpness < 0) sharpness = 0` (Config.h:40) -- and is undefined for the values refused here.
+bool floats_valid(const ovrfsr_config *cfg)
+{
+    if (!std::isfinite(cfg->radius) || cfg->radius < 0.0f) return false;
+    if (!std::isfinite(cfg->sharpness) || !std::isfinite(cfg->render_scale)) return false;
+    for (int i = 0; i < 4; ++i)
+        if (!(cfg->proj_centre[i] >= -1.0f && cfg->proj_centre[i] <= 2.0f)) return false; // NaN fails the comparison
+    return true;
+}
 bool config_valid(const ovrfsr_config *cfg)
 {
     return config_ok(cfg) && (cfg->precision == OVRFSR_PRECISION_FP32 || cfg->precision == OVRFSR_PRECISION_FP32_STRICT) &&
-           cfg->stage_mask >= 0 && cfg->stage_mask <= 2 && cfg->fused >= -1 && cfg->fused <= 1 && (cfg->pair_submit == 0 || cfg->pair_submit == 1);
+           cfg->stage_mask >= 0 && cfg->stage_mask <= 2 && cfg->fused >= -1 && cfg->fused <= 1 && (cfg->pair_submit == 0 || cfg->pair_submit == 1) &&
+           floats_valid(cfg);
 }
 
 // Nothing may unwind through the extern "C" boundary (header: "nothing here throws"): host-side containers of the launch
@@ -53,6 +66,23 @@ OVRFSR_API int ovrfsr_debug_tie_audit(unsigned long long counts[6], int reset)
     return ovrfsr::tie_audit_read(counts, reset != 0) == hipSuccess ? OVRFSR_OK : OVRFSR_ERR_HIP;
 }
 #endif
+
+#ifdef OVRFSR_BOUNDS
+// CHECKED BUILDS ONLY (-DOVRFSR_BOUNDS, fsr_bounds.h; not part of the ABI, not declared in include/openvr_fsr_amd.h, absent from the shipped
+// library): the current device's checked-accessor counters, summed over the two kernel translation units, n = ovrfsr_chk::kSlots values
+// (layout: fsr_bounds.h); and the self-test launch.  tests/test_gpu_bounds.py drives them.
+OVRFSR_API int ovrfsr_debug_bounds_slots(void) { return ovrfsr_chk::kSlots; }
+OVRFSR_API int ovrfsr_debug_bounds(unsigned long long *counts, int n, int reset)
+{
+    if (!counts || n != ovrfsr_chk::kSlots) return OVRFSR_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < n; ++i) counts[i] = 0;
+    if (ovrfsr::bounds_read_fsr(counts, reset != 0) != hipSuccess) return OVRFSR_ERR_HIP;
+    return ovrfsr::bounds_read_nis(counts, reset != 0) == hipSuccess ? OVRFSR_OK : OVRFSR_ERR_HIP;
+}
+OVRFSR_API int ovrfsr_debug_bounds_selftest(void) { return ovrfsr::bounds_selftest() == hipSuccess ? OVRFSR_OK : OVRFSR_ERR_HIP; }
+#endif
+
+OVRFSR_API int ovrfsr_pair_pending(const ovrfsr_ctx *ctx) { return ctx && ctx->pp && ctx->pp->PairPending() ? 1 : 0; }
 
 OVRFSR_API void ovrfsr_config_default(ovrfsr_config *cfg)
 {

@@ -117,8 +117,15 @@ static int config_from_json_impl(const char *text, size_t len, ovrfsr_config *cf
     if (cfg->sharpness < 0) cfg->sharpness = 0;
     cfg->render_scale = as_float(m, "fsr.renderScale", 1.0);
     cfg->radius = as_float(m, "fsr.radius", 0.5);
+    if (cfg->radius < 0) cfg->radius = 0; // the rule the reference applies to sharpness (Config.h:40), applied to the other field a negative
+                                          // value is undefined for (float -> uint32, PostProcessor.cpp:303): a file never yields a cfg create refuses
     cfg->debug_mode = as_bool(m, "fsr.debugMode", false);
     cfg->use_nis = as_bool(m, "fsr.useNIS", false);
+    // a literal that overflows float (1e999) or is not a number: "Could not read config file" -- struct defaults, like a parse error
+    if (!std::isfinite(cfg->sharpness) || !std::isfinite(cfg->radius) || !std::isfinite(cfg->render_scale)) {
+        ovrfsr_config_default(cfg);
+        return OVRFSR_ERR_INVALID_ARGUMENT;
+    }
     return OVRFSR_OK;
 }
 
@@ -133,6 +140,31 @@ OVRFSR_API int ovrfsr_config_from_json(const char *text, size_t len, ovrfsr_conf
         return OVRFSR_ERR_OUT_OF_MEMORY;
     }
 }
+
+// IEEE binary16 -> float, exact (plain integer code: this translation unit also builds with compilers that have no _Float16 in C++)
+static float half_bits_to_float(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) u = sign;
+        else { int s = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++s; } u = sign | ((uint32_t)(113 - s) << 23) | ((mm & 0x3ffu) << 13); } // subnormal
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f; std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// What the capture writers accept: the rules ovrfsr_apply puts on caller images (PostProcessor::CheckImage: size, pitch, alignment).
+// A pitch below width * texel would make the row loops read past the host copy (round 6).
+static bool capture_image_ok(const ovrfsr_image *img, uint32_t tb)
+{
+    return img->width != 0 && img->height != 0 && img->width <= 16384u && img->height <= 16384u && img->pitch_bytes >= img->width * tb &&
+           img->pitch_bytes % tb == 0 && (uint64_t)img->pitch_bytes * img->height <= 0x100000000ull && reinterpret_cast<uintptr_t>(img->data) % tb == 0;
+}
+// bytes of the image as it sits in memory: the last row ends with its last texel, not with its pitch (a view into a larger
+// allocation owns nothing behind that)
+static size_t capture_span(const ovrfsr_image *img, uint32_t tb) { return (size_t)(img->height - 1) * img->pitch_bytes + (size_t)img->width * tb; }
 
 // Binary PPM (P6) of a device image; RGBA16F/32F/RGB10A2 are converted like a UNORM8 store.  Synchronises `stream`.
 static int save_ppm_impl(const ovrfsr_image *img, const char *path, void *stream);
@@ -150,7 +182,8 @@ static int save_ppm_impl(const ovrfsr_image *img, const char *path, void *stream
     const bool ten = img->format == OVRFSR_FORMAT_RGB10A2_UNORM;
     const bool bgra = img->format == OVRFSR_FORMAT_BGRA8_UNORM;
     const size_t tb = img->format == OVRFSR_FORMAT_RGBA8_UNORM || ten || bgra ? 4 : img->format == OVRFSR_FORMAT_RGBA16F ? 8 : 16;
-    std::vector<unsigned char> host((size_t)img->pitch_bytes * img->height);
+    if (!capture_image_ok(img, (uint32_t)tb)) return OVRFSR_ERR_INVALID_ARGUMENT;
+    std::vector<unsigned char> host(capture_span(img, (uint32_t)tb));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemcpyAsync(host.data(), img->data, host.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return OVRFSR_ERR_HIP;
     if (hipStreamSynchronize(s) != hipSuccess) return OVRFSR_ERR_HIP;
@@ -166,7 +199,7 @@ static int save_ppm_impl(const ovrfsr_image *img, const char *path, void *stream
                 if (ten) { uint32_t v; std::memcpy(&v, src + x * 4, 4); row[x * 3 + c] = q((float)((v >> (10 * c)) & 1023u) / 1023.0f); }
                 else if (tb == 4) row[x * 3 + c] = src[x * 4 + (bgra ? 2 - c : c)];
                 else if (tb == 16) { float v; std::memcpy(&v, src + x * 16 + c * 4, 4); row[x * 3 + c] = q(v); }
-                else { _Float16 h; std::memcpy(&h, src + x * 8 + c * 2, 2); row[x * 3 + c] = q((float)h); }
+                else { uint16_t h; std::memcpy(&h, src + x * 8 + c * 2, 2); row[x * 3 + c] = q(half_bits_to_float(h)); }
             }
         std::fwrite(row.data(), 1, row.size(), f);
     }
@@ -182,8 +215,10 @@ static int save_dds_impl(const ovrfsr_image *img, const char *path, void *stream
     if (!img || !img->data || !path || img->format > OVRFSR_FORMAT_BGRA8_UNORM || img->width == 0 || img->height == 0) return OVRFSR_ERR_INVALID_ARGUMENT;
     // DXGI_FORMAT_R8G8B8A8_UNORM = 28, R16G16B16A16_FLOAT = 10, R32G32B32A32_FLOAT = 2, R10G10B10A2_UNORM = 24, B8G8R8A8_UNORM = 87
     static const uint32_t dxgi[5] = {28u, 10u, 2u, 24u, 87u}, bytes[5] = {4u, 8u, 16u, 4u, 4u};
-    const uint32_t tb = bytes[img->format], rowBytes = img->width * tb;
-    std::vector<unsigned char> host((size_t)img->pitch_bytes * img->height);
+    const uint32_t tb = bytes[img->format];
+    if (!capture_image_ok(img, tb)) return OVRFSR_ERR_INVALID_ARGUMENT;
+    const uint32_t rowBytes = img->width * tb;
+    std::vector<unsigned char> host(capture_span(img, tb));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (hipMemcpyAsync(host.data(), img->data, host.size(), hipMemcpyDeviceToHost, s) != hipSuccess) return OVRFSR_ERR_HIP;
     if (hipStreamSynchronize(s) != hipSuccess) return OVRFSR_ERR_HIP;

@@ -57,22 +57,34 @@ void rcas_con(uint32_t con[4], float stops)
     con[3] = 0;
 }
 
+// float -> uint32 as the reference's `(uint32_t)x` gives it wherever that is defined (0 <= x < 2^32: truncation), and TOTAL elsewhere:
+// NaN and negative values give 0, values >= 2^32 give 0xffffffff -- the saturating ftou of the shader model the cbuffer is read by.
+// The C++ cast itself is undefined behaviour outside the range (PostProcessor.cpp:298-305 has the same hazard; x86 happens to
+// produce 0x80000000-flavoured garbage): a C ABI that promises "nothing here throws" does not inherit it.  oracle/fsr_oracle.c
+// (ovo_mask_constants) converts the same way.
+static inline uint32_t f2u_sat(float x)
+{
+    if (!(x > 0.0f)) return 0u;                 // NaN, -0, negatives
+    if (x >= 4294967296.0f) return 0xffffffffu; // +inf included
+    return (uint32_t)x;
+}
+
 void mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t outW, uint32_t outH, const float proj[4],
                     float cfgRadius, int onlyOneEye, int eye)
 {
     // every value is a float expression truncated into a uint32 cbuffer slot
     if (onlyOneEye) {
         const float px = eye ? proj[2] : proj[0], py = eye ? proj[3] : proj[1];
-        centre[0] = centre[2] = (uint32_t)(outW * px);
-        centre[1] = centre[3] = (uint32_t)(outH * py);
+        centre[0] = centre[2] = f2u_sat(outW * px);
+        centre[1] = centre[3] = f2u_sat(outH * py);
     } else {
         const uint32_t half = outW / 2; // integer halving first (PostProcessor.cpp:298,300)
-        centre[0] = (uint32_t)(half * proj[0]);
-        centre[1] = (uint32_t)(outH * proj[1]);
-        centre[2] = (uint32_t)(half * (1 + proj[2]));
-        centre[3] = (uint32_t)(outH * proj[3]);
+        centre[0] = f2u_sat(half * proj[0]);
+        centre[1] = f2u_sat(outH * proj[1]);
+        centre[2] = f2u_sat(half * (1 + proj[2]));
+        centre[3] = f2u_sat(outH * proj[3]);
     }
-    radius[0] = (uint32_t)(0.5f * cfgRadius * outH);
+    radius[0] = f2u_sat(0.5f * cfgRadius * outH);
     radius[1] = radius[0] * radius[0];
     radius[2] = outW;
     radius[3] = outH;

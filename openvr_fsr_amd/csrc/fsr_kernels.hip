@@ -6,6 +6,7 @@
 #include <type_traits>
 #include "fsr_params.h"
 #include "fsr_launch.h"
+#include "fsr_bounds.h"
 
 #ifdef OVRFSR_TIE_AUDIT
 // AUDIT BUILD (-DOVRFSR_TIE_AUDIT, never shipped): every pixel the product EASU resolves is resolved a second time in the reference's
@@ -55,9 +56,9 @@ template <int I, int O, bool M>
 static void easu_fast_go(int pitch, const EasuArgs &a, dim3 grid, hipStream_t s)
 {
     const size_t lds = (size_t)pitch * a.cellsH * 36 + (size_t)pitch * kLumPadRows * 4; // colour + analysis (float4) + luma planes + pad rows
-    if (pitch == 28) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 28, M>), grid, dim3(kThreads), lds, s, a);
-    else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 32, M>), grid, dim3(kThreads), lds, s, a);
-    else hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 40, M>), grid, dim3(kThreads), lds, s, a);
+    if (pitch == 28) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 28, M>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
+    else if (pitch == 32) hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 32, M>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
+    else hipLaunchKernelGGL((ovrfsr_fast::easu_fast_kernel<I, O, 40, M>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
 }
 
 template <int I, int O>
@@ -65,10 +66,10 @@ static hipError_t easu_go(bool strict, const EasuArgs &a, dim3 grid, size_t lds,
 {
     const int pitch = easu_kernel_pitch(a.cellsW);
     const bool masked = a.m.mode[0] != MASK_ALL_INSIDE || a.m.mode[1] != MASK_ALL_INSIDE;
-    if (strict) hipLaunchKernelGGL((ovrfsr_strict::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    if (strict) hipLaunchKernelGGL((ovrfsr_strict::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
     // footprints wider than the fixed pitches, and the 10-bit format (a quantised destination without a near-tie guard of
     // its own): the generic kernel, whose resolve is the reference-order one in every build
-    else if (pitch == 0 || I == FMT_RGB10A2 || O == FMT_RGB10A2) hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, a);
+    else if (pitch == 0 || I == FMT_RGB10A2 || O == FMT_RGB10A2) hipLaunchKernelGGL((ovrfsr_fast::easu_kernel<I, O>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
     else if (masked) easu_fast_go<I, O, true>(pitch, a, grid, s);
     else easu_fast_go<I, O, false>(pitch, a, grid, s);
     return hipGetLastError();
@@ -181,17 +182,17 @@ static hipError_t fused_go3(bool strict, const FusedArgs &a, dim3 grid, size_t l
         static std::atomic<uint64_t> done{0};
         const hipError_t e = raise(reinterpret_cast<const void *>(&ovrfsr_strict::fused_kernel<I, M, O, 0>), done);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((ovrfsr_strict::fused_kernel<I, M, O, 0>), grid, dim3(kThreads), lds, s, a);
+        hipLaunchKernelGGL((ovrfsr_strict::fused_kernel<I, M, O, 0>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
     } else if (pitch == 32) {
         static std::atomic<uint64_t> done{0};
         const hipError_t e = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>), done);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, a);
+        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 32, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, with_lds(a, lds));
     } else if (pitch == 40) {
         static std::atomic<uint64_t> done{0};
         const hipError_t e = raise(reinterpret_cast<const void *>(&ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>), done);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, a);
+        hipLaunchKernelGGL((ovrfsr_fast::fused_kernel<I, M, O, 40, kFusedThreads>), grid, dim3(kFusedThreads), lds, s, with_lds(a, lds));
     } else {
         return hipErrorInvalidValue;
     }
@@ -256,13 +257,13 @@ static hipError_t outside_staged_go(int mid_fmt, const OutsideArgs &a, dim3 grid
     if constexpr (I != FMT_RGBA8) {
         return hipErrorInvalidValue;
     } else if constexpr (TH == 24) { // NIS DirectCopy
-        hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<24, I, O, FMT_RGBA32F>), grid, dim3(8 * 24), lds, s, a);
+        hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<24, I, O, FMT_RGBA32F>), grid, dim3(8 * 24), lds, s, with_lds(a, lds));
     } else {
         switch (mid_fmt) { // RGBA8 sources: a UNORM8 or a float intermediate, or the EASU pass alone
-        case FMT_RGBA8: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA8>), grid, dim3(256), lds, s, a); break;
-        case FMT_RGBA32F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA32F>), grid, dim3(256), lds, s, a); break;
+        case FMT_RGBA8: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA8>), grid, dim3(256), lds, s, with_lds(a, lds)); break;
+        case FMT_RGBA32F: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, FMT_RGBA32F>), grid, dim3(256), lds, s, with_lds(a, lds)); break;
         case FMT_RGBA16F: return hipErrorInvalidValue;
-        default: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, -1>), grid, dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((ovrfsr_fast::outside_staged_kernel<32, I, O, -1>), grid, dim3(256), lds, s, with_lds(a, lds)); break;
         }
     }
     return hipGetLastError();
@@ -323,6 +324,66 @@ hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t s
     hipLaunchKernelGGL(bgra_to_rgba_kernel, dim3((w + 255) / 256, h, batch), dim3(256), 0, s, src, srcPitch, srcStride, dst, w, h);
     return hipGetLastError();
 }
+
+#ifdef OVRFSR_BOUNDS
+// Drives the checked accessors through every kind of violation exactly once (tests/test_gpu_bounds.py asserts the counts): proof that a
+// zero from a campaign means "nothing out of bounds", not "nothing checked".  64 threads, 1024 bytes of dynamic LDS.
+__global__ void bounds_selftest_kernel(const uint8_t *img, uint32_t ldsBytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using namespace ovrfsr_chk;
+    const int lane = threadIdx.x;
+    ptr<float> plane = carve<float>(reinterpret_cast<float *>(smem), 64, 16, K_SELFTEST, smem, ldsBytes);
+    plane[lane] = (float)lane;                                   // 64 accesses inside the plane
+    __syncthreads();
+    float sink = 0.0f;
+    if (lane == 0) sink += plane[64 + 3];                        // inside the declared pad: 1 pad access
+    if (lane == 1) sink += plane[64 + 16];                       // behind the pad: out of bounds
+    if (lane == 2) sink += plane[-1];                            // in front of the plane: out of bounds
+    // a 12 x 4 image of 4-byte texels with a 64-byte row pitch
+    const ptr<const uint8_t> im = image<const uint8_t>(img, 64, 12, 4, 4, K_IMAGE_IN);
+    if (lane == 3) sink += (float)*at<const uint32_t>(im + 48);            // row 0, pitch padding: out of bounds
+    if (lane == 4) sink += (float)*at<const uint32_t>(im + (3 * 64 + 44)); // the last texel: fine
+    if (lane == 5) sink += (float)*at<const uint32_t>(im + (3 * 64 + 48)); // behind the last texel: out of bounds
+    if (lane == 6) sink += (float)*at<const uint32_t>(im + 46);            // straddles the end of row 0: out of bounds
+    // a plane carved beyond the launch's dynamic LDS: one K_LDS_ALLOC record (thread 0)
+    const ptr<float> beyond = carve<float>(reinterpret_cast<float *>(smem) + 250, 16, 0, K_SELFTEST, smem, ldsBytes);
+    if (sink == 12345.678f && beyond.p) plane[0] = sink; // keep the reads alive
+}
+hipError_t bounds_selftest()
+{
+    uint8_t *img = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&img), 4 * 64);
+    if (e != hipSuccess) return e;
+    e = hipMemset(img, 1, 4 * 64);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bounds_selftest_kernel, dim3(1), dim3(64), 1024, nullptr, img, 1024u);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(img);
+    return e;
+}
+static hipError_t bounds_read_tu(unsigned long long *out, bool reset)
+{
+    unsigned long long c[ovrfsr_chk::kSlots];
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(c, HIP_SYMBOL(ovrfsr_chk::g_counts), sizeof c);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < ovrfsr_chk::kFirstRec; ++i) out[i] += c[i];
+    if (out[ovrfsr_chk::kFirstRec] == 0 && c[ovrfsr_chk::kFirstRec] != 0)
+        for (int i = ovrfsr_chk::kFirstRec; i < ovrfsr_chk::kSlots; ++i) out[i] = c[i];
+    if (reset) {
+        for (unsigned long long &v : c) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(ovrfsr_chk::g_counts), c, sizeof c);
+    }
+    return e;
+}
+hipError_t bounds_read_fsr(unsigned long long *out, bool reset) { return bounds_read_tu(out, reset); }
+#else
+hipError_t bounds_read_fsr(unsigned long long *, bool) { return hipErrorNotSupported; }
+hipError_t bounds_selftest() { return hipErrorNotSupported; }
+#endif
 
 // audit build: read (and optionally clear) the current device's counters; product build: hipErrorNotSupported
 hipError_t tie_audit_read(unsigned long long out[6], bool reset)

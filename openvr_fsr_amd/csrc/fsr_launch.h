@@ -21,4 +21,16 @@ hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt
 hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a, uint32_t nGroups, uint32_t batch, hipStream_t s);
 hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a, uint32_t batch, hipStream_t s);
 hipError_t tie_audit_read(unsigned long long out[6], bool reset); // -DOVRFSR_TIE_AUDIT builds only (fsr_kernels.hip)
+// -DOVRFSR_BOUNDS builds only (fsr_bounds.h): the checked accessors' counters of the current device, one array per kernel translation
+// unit (fsr_kernels.hip / nis_kernels.hip), ADDED into out[ovrfsr_chk::kSlots] (the first-hit record: copied if out has none yet);
+// and a launch that drives the accessors through every kind of violation once (fsr_kernels.hip)
+hipError_t bounds_read_fsr(unsigned long long *out, bool reset);
+hipError_t bounds_read_nis(unsigned long long *out, bool reset);
+hipError_t bounds_selftest();
+// the kernel argument block as launched: checked builds add the dynamic LDS size of the launch
+#ifdef OVRFSR_BOUNDS
+template <typename A> static inline A with_lds(A a, size_t lds) { a.ldsBytes = (uint32_t)lds; return a; }
+#else
+template <typename A> static inline const A &with_lds(const A &a, size_t) { return a; }
+#endif
 } // namespace ovrfsr

@@ -34,6 +34,14 @@ constexpr uint64_t kRcasResident = 8ull * 256; // workgroups of rcas_dpp_kernel 
 // workgroup-uniform, but the hardware has no scalar divide: `tile / tilesX` costs ~20 VALU instructions per thread.
 static inline uint32_t div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)(0x100000000ull / d) + 1u; }
 
+// -DOVRFSR_BOUNDS builds (fsr_bounds.h) tell every kernel how much dynamic LDS its launch allocated, so that the planes it carves
+// can be checked against it; the product build's argument blocks do not carry the field.
+#ifdef OVRFSR_BOUNDS
+#define OVRFSR_ARGS_LDS_BYTES uint32_t ldsBytes = 0;
+#else
+#define OVRFSR_ARGS_LDS_BYTES
+#endif
+
 struct BatchView {          // image i of a batch lives at base + i*stride
     const uint8_t *in;
     uint8_t *out;
@@ -74,6 +82,7 @@ struct EasuArgs {
     float tieHalfMin;         // near-tie guard of RGBA16F stores: values below it are not guarded (see half_tie_code); +inf = off
     uint32_t ringStrips;      // mask-sorted form: a listed tile with no group inside the radius is a RING tile whose output only
                               // feeds the RCAS taps of inside neighbours -- write just the edge pixels those taps read
+    OVRFSR_ARGS_LDS_BYTES
 };
 
 // LDS-staged bilinear fallback / DirectCopy of mask-sorted tiles entirely outside the radius (product build,
@@ -83,13 +92,14 @@ struct OutsideArgs {
     uint32_t tilesX;          // tiles (32 x TH output pixels) per row
     uint32_t tilesXMagic;     // div_magic(tilesX), filled by the launcher
     const uint32_t *tileList;
-    const BilinTap *bilX;     // host-built column / row taps (see BilinTap), padded by 64 entries
+    const BilinTap *bilX;     // host-built column / row taps (see BilinTap); column taps padded to a multiple of 32 with copies of the last
     const BilinTap *bilY;
     uint32_t debug;
     uint32_t lds_cols, lds_rows; // LDS texel plane extent (set by launch_outside_staged from the tap tables' host copy)
     const uint32_t *tileRec;     // 4 dwords per list entry (host-built, parallel to tileList): ox0 | oy0 << 16, (X0+1) | (Y0+1) << 16,
                                  // colsN | rowsN << 8, 0 -- tile origin, footprint origin and extent (see outside_staged_kernel)
     uint32_t nTiles;             // list length; the kernel is persistent: block b walks entries b, b + gridDim.x, ...
+    OVRFSR_ARGS_LDS_BYTES
 };
 
 struct RcasArgs {
@@ -120,6 +130,7 @@ struct FusedArgs {
     float tieHalfMin;         // near-tie guard of a half intermediate (see EasuArgs)
     const BilinTap *bilX;     // [outW], [outH] column / row taps of the bilinear fallback (product build: groups outside the
     const BilinTap *bilY;     // radius inside a tile that touches it take their texels from the LDS colour plane)
+    OVRFSR_ARGS_LDS_BYTES
 };
 
 struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) minus the unused viewport fields
@@ -141,6 +152,7 @@ struct NisArgs {            // the NISConfig cbuffer (NIS_Upscale.hlsl:28-68) mi
     const BilinTap *bilX;     // DirectCopy taps of the mask-sorted outside kernel (see OutsideArgs)
     const BilinTap *bilY;
     uint32_t outsideCols, outsideRows; // largest bilinear footprint of a 32x24 group
+    OVRFSR_ARGS_LDS_BYTES
 };
 
 } // namespace ovrfsr

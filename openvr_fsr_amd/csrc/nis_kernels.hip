@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include "fsr_params.h"
 #include "fsr_launch.h"
+#include "fsr_bounds.h"
 
 namespace ovrfsr_fast {
 #define OVRFSR_STRICT 0
@@ -30,11 +31,11 @@ static hipError_t scaler_go(bool strict, const NisArgs &a, dim3 grid, size_t lds
 {
     const int pitch = nis_pitch(a.cellsW);
     if (pitch == 32) {
-        if (strict) hipLaunchKernelGGL((ovrfsr_strict::nis_scaler_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, a);
-        else hipLaunchKernelGGL((ovrfsr_fast::nis_scaler_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, a);
+        if (strict) hipLaunchKernelGGL((ovrfsr_strict::nis_scaler_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
+        else hipLaunchKernelGGL((ovrfsr_fast::nis_scaler_kernel<I, O, 32>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
     } else if (pitch == 40) {
-        if (strict) hipLaunchKernelGGL((ovrfsr_strict::nis_scaler_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, a);
-        else hipLaunchKernelGGL((ovrfsr_fast::nis_scaler_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, a);
+        if (strict) hipLaunchKernelGGL((ovrfsr_strict::nis_scaler_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
+        else hipLaunchKernelGGL((ovrfsr_fast::nis_scaler_kernel<I, O, 40>), grid, dim3(kThreads), lds, s, with_lds(a, lds));
     } else {
         return hipErrorInvalidValue;
     }
@@ -98,6 +99,26 @@ hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a
     const size_t lds = nis_scaler_lds_bytes(a.cellsW, a.cellsH);
     OVRFSR_DISPATCH_FMT(scaler_go, prec == PREC_FP32_STRICT, a, grid, lds, s)
 }
+
+#ifdef OVRFSR_BOUNDS
+hipError_t bounds_read_nis(unsigned long long *out, bool reset)
+{
+    unsigned long long c[ovrfsr_chk::kSlots];
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(c, HIP_SYMBOL(ovrfsr_chk::g_counts), sizeof c);
+    if (e != hipSuccess) return e;
+    for (int i = 0; i < ovrfsr_chk::kFirstRec; ++i) out[i] += c[i];
+    if (out[ovrfsr_chk::kFirstRec] == 0 && c[ovrfsr_chk::kFirstRec] != 0)
+        for (int i = ovrfsr_chk::kFirstRec; i < ovrfsr_chk::kSlots; ++i) out[i] = c[i];
+    if (reset) {
+        for (unsigned long long &v : c) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(ovrfsr_chk::g_counts), c, sizeof c);
+    }
+    return e;
+}
+#else
+hipError_t bounds_read_nis(unsigned long long *, bool) { return hipErrorNotSupported; }
+#endif
 
 hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a_in, uint32_t batch, hipStream_t s)
 {

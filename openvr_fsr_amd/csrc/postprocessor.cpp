@@ -85,7 +85,7 @@ void PostProcessor::Join(hipStream_t user, hipStream_t aux)
 
 PostProcessor::~PostProcessor()
 {
-    Reset();
+    Reset(); // (frees a retired pair_submit image too)
     DeviceGuard guard(device_);
     if (auxStream_) (void)hipStreamDestroy(auxStream_);
     if (evFork_) (void)hipEventDestroy(evFork_);
@@ -109,10 +109,16 @@ int PostProcessor::Fail(int status, const std::string &what)
     return status;
 }
 
-void PostProcessor::Reset()
+void PostProcessor::Reset() { ResetKeeping(false); }
+
+// keepRetired: the implicit Reset of a size change (Apply) must not free the ctx-owned image a just-flushed pair_submit eye was handed in
+void PostProcessor::ResetKeeping(bool keepRetired)
 {
     DeviceGuard guard(device_); // resources live on the ctx's device, whatever the caller has selected
-    havePending_ = false;       // a recorded LEFT of cfg.pair_submit is dropped (header)
+    if (!keepRetired && retired_) { (void)hipFree(retired_); retired_ = nullptr; }
+    havePending_ = false;       // a recorded first eye of cfg.pair_submit is dropped (header)
+    lastApplyRecorded_ = false;
+    if (!keepRetired) { pairFirstEye_ = -1; pairDefer_ = true; lastEye_ = -1; } // an explicit reset forgets the learned submission order
     enabled_ = true;
     initialized_ = false;
     if (swizzled_) (void)hipFree(swizzled_);
@@ -130,6 +136,7 @@ void PostProcessor::Reset()
     nisCoefDev_ = nullptr;
     bilinDev_ = nullptr;
     bilinHost_.clear(); // never let taps of a previous configuration reach PrepareTileLists' footprint records
+    bilYOff_ = 0;
     upscaled_ = sharpened_ = nullptr;
     upscaledBytes_ = sharpenedBytes_ = 0;
     lastSubmittedTexture_ = nullptr;
@@ -287,8 +294,15 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
     if (doUpscale_) {
         // column / row taps of the bilinear fallback / NIS DirectCopy (SampleLevel at pos/outSize, 8-bit sub-texel snap): same IEEE
         // operations as fsr_device.inc's bilinear_uv / fixed8, evaluated once per column and row instead of per pixel
+        // Layout: [ow column taps | copies of the last column tap up to a multiple of the tile width | oh row taps | 64 spare entries].
+        // The staged outside-tile kernel loads the column taps of every pixel QUAD of a 32-wide tile (outside_staged_kernel::issue_taps);
+        // the quads on and behind the last column must find VALID taps -- their pixels are never stored, but the taps index the kernel's
+        // LDS plane.  (Until round 6
+        // the row taps followed the column taps directly and that quad read row taps as column taps: out-of-plane LDS reads whose values
+        // were discarded -- found by the checked build, profiles/r06_bounds.txt.)
         std::vector<BilinTap> &taps = bilinHost_;
-        taps.assign((size_t)ow + oh + 64, BilinTap{0, 0.0f}); // padding: kernels read whole quads / clamp-free rows
+        bilYOff_ = (ow + (uint32_t)kTileW - 1u) & ~((uint32_t)kTileW - 1u);
+        taps.assign((size_t)bilYOff_ + oh + 64, BilinTap{0, 0.0f});
         auto fill = [](BilinTap *t, uint32_t outN, uint32_t inN) {
             for (uint32_t o = 0; o < outN; ++o) {
                 volatile float u = (float)o / (float)outN;
@@ -301,7 +315,8 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
             }
         };
         fill(taps.data(), ow, in.width);
-        fill(taps.data() + ow, oh, in.height);
+        for (uint32_t o = ow; o < bilYOff_; ++o) taps[o] = taps[ow - 1];
+        fill(taps.data() + bilYOff_, oh, in.height);
         // largest [first tap, last tap + 1] span of a tile: the LDS plane of the staged outside-tile kernel
         auto span = [](const BilinTap *t, uint32_t outN, uint32_t tile) {
             int best = 2;
@@ -312,8 +327,8 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
             return (uint32_t)best;
         };
         outsideCols_ = span(taps.data(), ow, 32);
-        outsideRows_[0] = span(taps.data() + ow, oh, 32);
-        outsideRows_[1] = span(taps.data() + ow, oh, 24);
+        outsideRows_[0] = span(taps.data() + bilYOff_, oh, 32);
+        outsideRows_[1] = span(taps.data() + bilYOff_, oh, 24);
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&bilinDev_), taps.size() * sizeof(BilinTap));
         if (e == hipSuccess) e = hipMemcpy(bilinDev_, taps.data(), taps.size() * sizeof(BilinTap), hipMemcpyHostToDevice);
         if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("bilinear tap tables: ") + hipGetErrorString(e));
@@ -451,8 +466,8 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
     // (first column / row tap) and extent ([first tap, last tap + 1], what the kernel used to fetch through a chain of
     // dependent scalar loads: tile index -> tap tables)
     std::vector<uint32_t> recs(lists.size() * 4, 0u);
-    if (bilinHost_.size() >= (size_t)outputWidth_ + outputHeight_) {
-        const BilinTap *bx = bilinHost_.data(), *by = bilinHost_.data() + outputWidth_;
+    if (bilinHost_.size() >= (size_t)bilYOff_ + outputHeight_) {
+        const BilinTap *bx = bilinHost_.data(), *by = bilinHost_.data() + bilYOff_;
         const uint32_t rowsCap = outsideRows_[tileH == 24 ? 1 : 0];
         for (size_t i = 0; i < lists.size(); ++i) {
             const uint32_t t = lists[i], tyi = t / tx, txi = t - tyi * tx;
@@ -526,7 +541,7 @@ void PostProcessor::FillNis(NisArgs &a, int firstEye, int alternate) const
     a.coefScale = nisCoefDev_;
     a.coefUsm = nisCoefDev_ + 512;
     a.cellsW = nisCellsW_; a.cellsH = nisCellsH_;
-    a.bilX = bilinDev_; a.bilY = bilinDev_ ? bilinDev_ + outputWidth_ : nullptr;
+    a.bilX = bilinDev_; a.bilY = bilinDev_ ? bilinDev_ + bilYOff_ : nullptr;
     a.outsideCols = outsideCols_; a.outsideRows = outsideRows_[1];
 }
 
@@ -629,7 +644,7 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
     std::memcpy(&a.cx, &easuCon_[2], 4); std::memcpy(&a.cy, &easuCon_[3], 4);
     FillMask(a.m, firstEye, alternate);
     a.cellsW = cellsW_; a.cellsH = cellsH_;
-    a.bilX = bilinDev_; a.bilY = bilinDev_ + outputWidth_;
+    a.bilX = bilinDev_; a.bilY = bilinDev_ + bilYOff_;
     a.tileList = nullptr;
     a.tileRec = nullptr;
     a.tieHalfMin = TieHalfMin();
@@ -647,9 +662,13 @@ void PostProcessor::FillEasu(EasuArgs &a, const ovrfsr_image &in, size_t inStrid
 // 9e-4 are left alone; +inf (guard off) when no sharpening pass follows the upscale.
 float PostProcessor::TieHalfMin() const
 {
-    // diagnostic: OVRFSR_TIE_HALF_MIN=<x> guards half stores from x upwards whatever follows the upscale -- lets a test (and the audit
-    // build, tools/debug/tie_audit.py) read the guarded half intermediate directly as the output of an EASU-only pass
-    if (const char *e = std::getenv("OVRFSR_TIE_HALF_MIN")) { const float v = (float)std::atof(e); if (v > 0.0f) return v; }
+#ifdef OVRFSR_TIE_AUDIT
+    // AUDIT builds only (round 6; the shipped library never reads it: a stray environment variable must not change product numerics):
+    // OVRFSR_TIE_HALF_MIN=<x> guards half stores from x upwards whatever follows the upscale -- lets tools/debug/tie_audit.py and
+    // tests/test_gpu_formats.py read the guarded half intermediate directly as the output of an EASU-only pass.  Read once.
+    static const float forced = [] { const char *e = std::getenv("OVRFSR_TIE_HALF_MIN"); return e ? (float)std::atof(e) : 0.0f; }();
+    if (forced > 0.0f) return forced;
+#endif
     if (!(doUpscale_ && doSharpen_) || cfg_.use_nis) return INFINITY;
     float sharp;
     std::memcpy(&sharp, &rcasCon_[0], 4);
@@ -759,7 +778,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
     a.tilesY = (out.height + kTileH - 1) / kTileH;
     a.tileList = nullptr;
     a.tieHalfMin = TieHalfMin();
-    a.bilX = bilinDev_; a.bilY = bilinDev_ + outputWidth_;
+    a.bilX = bilinDev_; a.bilY = bilinDev_ + bilYOff_;
     hipError_t e = hipSuccess;
     if (!tileListDev_) {
         e = launch_fused(cfg_.precision, (int)in.format, (int)IntermediateFormat(), (int)out.format, a, n, stream);
@@ -844,6 +863,10 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
     const bool inTen = in.format == OVRFSR_FORMAT_RGB10A2_UNORM, outTen = out.format == OVRFSR_FORMAT_RGB10A2_UNORM;
     if ((outTen && !inTen) || (inTen && !outTen && out.format != OVRFSR_FORMAT_RGBA32F))
         return Fail(OVRFSR_ERR_UNSUPPORTED, "RGB10A2 images pair with an RGB10A2 (or RGBA32F) destination only");
+    // (a float intermediate in front of a 10-bit destination is a kernel pair nobody builds: refused here, before anything is launched,
+    // instead of surfacing as a launch error behind the EASU pass -- found by the round-6 format sweep)
+    if (outTen && doUpscale_ && doSharpen_ && IntermediateFormat() != OVRFSR_FORMAT_RGB10A2_UNORM)
+        return Fail(OVRFSR_ERR_UNSUPPORTED, "RGB10A2 pipelines keep a 10-bit intermediate (quantize_intermediate = 1)");
     const bool timing = cfg_.debug_mode && queries_[0].start;
     if (timing) (void)hipEventRecord(queries_[currentQuery_].start, stream);
     int rc = OVRFSR_OK;
@@ -904,8 +927,19 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
 
     if (initialized_ && (in->width != inputWidth_ || in->height != inputHeight_ || in->format != inputFormat_)) {
-        if (havePending_) { rc = FlushPending(stream); if (rc != OVRFSR_OK) return rc; } // the recorded LEFT belongs to the old resources
-        Reset(); // "Texture size changed, recreating resources" (:139-142)
+        bool keep = false;
+        if (havePending_) { // the recorded eye belongs to the old resources
+            const uint8_t *po = static_cast<const uint8_t *>(pendingOut_.data), *sb = static_cast<const uint8_t *>(sharpened_);
+            const bool owned = sb && po >= sb && po < sb + sharpenedBytes_;
+            rc = FlushPending(stream);
+            if (rc != OVRFSR_OK) return rc;
+            if (owned) { // its result was written to a ctx-owned image the caller already holds: that image outlives the rebuild
+                if (retired_) (void)hipFree(retired_);
+                retired_ = sharpened_; sharpened_ = nullptr; sharpenedBytes_ = 0;
+                keep = true;
+            }
+        }
+        ResetKeeping(keep); // "Texture size changed, recreating resources" (:139-142)
     }
     if (!initialized_) {
         textureContainsOnlyOneEye_ = std::fabs(bounds->uMax - bounds->uMin) > .5f; // :146
@@ -916,7 +950,7 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
     // caller-owned or ctx-owned final image
     ovrfsr_image dst;
     const bool stages = doUpscale_ || doSharpen_;
-    // cfg.pair_submit (header): one texture per eye and something to launch -> LEFT is recorded, RIGHT launches both
+    // cfg.pair_submit (header): one texture per eye and something to launch -> the first eye of a frame is recorded, the other eye launches both
     const bool pairMode = cfg_.pair_submit != 0 && textureContainsOnlyOneEye_ && stages;
     if (out->data) {
         rc = CheckImage(out, "out");
@@ -939,33 +973,38 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
     // (sharpen-only mode, where the sizes agree) is the same race
     if (stages && RangesOverlap(*in, 0, dst, 0, 1)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output images overlap");
 
+    lastApplyRecorded_ = false;
     if (pairMode) {
-        if (eye == OVRFSR_EYE_LEFT) { // record; a LEFT still waiting is processed on its own first
-            if (havePending_) { rc = FlushPending(stream); if (rc != OVRFSR_OK) return rc; }
-            pendingIn_ = *in; pendingOut_ = dst; havePending_ = true;
-            lastSubmittedTexture_ = in->data;
-            eyeCount_ = (eyeCount_ + 1) % 2;
-            outputTexture_ = dst;
-            *out = dst;
-            return OVRFSR_OK;
-        }
-        if (havePending_) {
-            // both eyes as ONE batch of two: image 0 = the eye whose input lies lower in memory, image 1 = base + stride.  The outputs must
-            // be laid out the same way round; anything else (other size / pitch / format, overlapping or oppositely ordered images) takes
-            // the two single launches below
-            const ovrfsr_image &li = pendingIn_, &lo = pendingOut_, &ri = *in, &ro = dst;
-            const uintptr_t lip = reinterpret_cast<uintptr_t>(li.data), rip = reinterpret_cast<uintptr_t>(ri.data);
-            const uintptr_t lop = reinterpret_cast<uintptr_t>(lo.data), rop = reinterpret_cast<uintptr_t>(ro.data);
-            const bool same = li.width == ri.width && li.height == ri.height && li.pitch_bytes == ri.pitch_bytes && li.format == ri.format &&
-                              lo.width == ro.width && lo.height == ro.height && lo.pitch_bytes == ro.pitch_bytes && lo.format == ro.format;
-            const bool leftFirst = lip < rip;
-            const size_t inStride = leftFirst ? rip - lip : lip - rip, outStride = leftFirst ? rop - lop : lop - rop;
-            const bool ordered = lip != rip && lop != rop && (leftFirst ? lop < rop : rop < lop);
-            if (same && ordered && inStride >= (size_t)li.pitch_bytes * li.height && outStride >= (size_t)lo.pitch_bytes * lo.height &&
-                inStride % texel_bytes(li.format) == 0 && outStride % texel_bytes(lo.format) == 0 &&
-                !RangesOverlap(leftFirst ? li : ri, inStride, leftFirst ? lo : ro, outStride, 2)) {
+        // Pairing is by ARRIVAL order (round 6: games submit L,R or R,L; until then only LEFT was recorded and an R,L game had every LEFT
+        // batched with the NEXT frame's RIGHT).  A small state machine keeps a disturbed sequence from turning into a standing one-frame lag:
+        //   pending, other eye arrives   -> both as one batch of two; that pair's first eye is remembered as the frame's first eye
+        //   pending, SAME eye again      -> the older one alone, this one alone, and no more recording until the other eye shows up
+        //                                   (a host that submits one eye per frame, or a frame that lost an eye)
+        //   nothing pending              -> recorded if it is (or may be) a frame's first eye; a frame's SECOND eye with nothing pending
+        //                                   (its partner was flushed by a batch call or a size change) is processed at once
+        const int prevEye = lastEye_;
+        lastEye_ = eye;
+        if (havePending_ && pendingEye_ == eye) {
+            rc = FlushPending(stream);
+            if (rc != OVRFSR_OK) return rc;
+            pairDefer_ = false; // falls through to the single launch below
+        } else if (havePending_) {
+            // image 0 = the recorded eye, image 1 = this one.  Image 1 lives at base + stride with the strides taken modulo 2^64 (the kernels
+            // add `i * stride` to a 64-bit base, i in {0, 1}): it may lie above or below image 0, inputs and outputs independently.  Images
+            // that differ in size / pitch / format, one texture submitted for both eyes, or outputs that overlap an input or each other
+            // take two single launches instead.
+            const ovrfsr_image &fi = pendingIn_, &fo = pendingOut_, &si = *in, &so = dst;
+            const bool same = fi.width == si.width && fi.height == si.height && fi.pitch_bytes == si.pitch_bytes && fi.format == si.format &&
+                              fo.width == so.width && fo.height == so.height && fo.pitch_bytes == so.pitch_bytes && fo.format == so.format;
+            const size_t inStride = (size_t)(reinterpret_cast<uintptr_t>(si.data) - reinterpret_cast<uintptr_t>(fi.data));
+            const size_t outStride = (size_t)(reinterpret_cast<uintptr_t>(so.data) - reinterpret_cast<uintptr_t>(fo.data));
+            const bool disjoint = fi.data != si.data && !RangesOverlap(fo, 0, so, 0, 1) && !RangesOverlap(fi, 0, so, 0, 1) && !RangesOverlap(si, 0, fo, 0, 1) &&
+                                  !RangesOverlap(fi, 0, fo, 0, 1) && !RangesOverlap(si, 0, so, 0, 1);
+            pairFirstEye_ = pendingEye_;
+            pairDefer_ = true;
+            if (same && disjoint && inStride % texel_bytes(fi.format) == 0 && outStride % texel_bytes(fo.format) == 0) {
                 havePending_ = false;
-                rc = ApplyPostProcess(2, leftFirst ? OVRFSR_EYE_LEFT : OVRFSR_EYE_RIGHT, 1, leftFirst ? li : ri, inStride, leftFirst ? lo : ro, outStride, stream);
+                rc = ApplyPostProcess(2, pendingEye_, 1, fi, inStride, fo, outStride, stream);
                 if (rc != OVRFSR_OK) return rc;
                 lastSubmittedTexture_ = in->data;
                 eyeCount_ = (eyeCount_ + 1) % 2;
@@ -973,8 +1012,19 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
                 *out = dst;
                 return OVRFSR_OK;
             }
-            rc = FlushPending(stream);
+            rc = FlushPending(stream); // then this eye alone, below
             if (rc != OVRFSR_OK) return rc;
+        } else if (!pairDefer_) {
+            if (prevEye >= 0 && prevEye != eye) pairDefer_ = true; // both eyes are back: pairs again from the next call on
+        } else if (pairFirstEye_ < 0 || pairFirstEye_ == eye) {
+            // the first eye of a frame: record it and hand out where its result will be
+            pendingIn_ = *in; pendingOut_ = dst; pendingEye_ = eye; havePending_ = true;
+            lastApplyRecorded_ = true;
+            lastSubmittedTexture_ = in->data;
+            eyeCount_ = (eyeCount_ + 1) % 2;
+            outputTexture_ = dst;
+            *out = dst;
+            return OVRFSR_OK;
         }
     }
     // a shared side-by-side texture is processed once, on the first Submit (:155-158)
@@ -1025,12 +1075,12 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     return ApplyPostProcess(n, firstEye, alternate, *in0, inStride, *out0, outStride, stream);
 }
 
-// cfg.pair_submit: the recorded LEFT submission on its own (no RIGHT followed it)
+// cfg.pair_submit: the recorded submission on its own (its other eye did not follow)
 int PostProcessor::FlushPending(hipStream_t stream)
 {
     if (!havePending_) return OVRFSR_OK;
     havePending_ = false;
-    return ApplyPostProcess(1, OVRFSR_EYE_LEFT, 0, pendingIn_, 0, pendingOut_, 0, stream);
+    return ApplyPostProcess(1, pendingEye_, 0, pendingIn_, 0, pendingOut_, 0, stream);
 }
 
 // PostProcessor.cpp:608-626: advance the ring and read the slot recorded kQueryCount-1 applies ago

@@ -33,6 +33,7 @@ public:
     int SetConfig(const ovrfsr_config &cfg);
     const ovrfsr_config &GetConfig() const { return cfg_; }
     const char *LastError() const { return lastError_.c_str(); }
+    bool PairPending() const { return lastApplyRecorded_ && havePending_; }
     int LastGpuTimeMs(float *ms);
     int AverageGpuTimeMs(float *ms, uint32_t *reports);
 
@@ -70,7 +71,8 @@ private:
     // NIS: the 256-byte NISConfig (PostProcessor.cpp:307-310) and the coefficient "textures" (:366-381)
     NisConstants nisConfig_ = {};
     float *nisCoefDev_ = nullptr; // coef_scale[512] | coef_usm[512]
-    BilinTap *bilinDev_ = nullptr; // [outW] column taps followed by [outH] row taps of the bilinear fallback
+    BilinTap *bilinDev_ = nullptr; // [outW] column taps (padded to a multiple of the tile width with copies of the last one), then [outH] row taps at bilYOff_
+    uint32_t bilYOff_ = 0;
     // mask-sorted EASU tile lists (product build, masked configs): per eye, tiles with any group inside the radius
     // and tiles entirely outside; the latter run through an LDS-free kernel at twice the occupancy
     uint32_t *tileListDev_ = nullptr;
@@ -87,9 +89,16 @@ private:
     // a ctx-owned auxiliary stream, forked from and joined back into the caller's stream with events
     hipStream_t auxStream_ = nullptr;
     hipEvent_t evFork_ = nullptr, evJoin_ = nullptr;
-    // cfg.pair_submit: the recorded LEFT submission of the current frame (see the header) and what it takes to launch it
+    // cfg.pair_submit: the recorded FIRST submission of the current frame (either eye; see the header) and what it takes to launch it
     bool havePending_ = false;
+    int pendingEye_ = 0;
+    int pairFirstEye_ = -1;          // the eye that opens a frame, learned from the last completed pair (-1: not known yet)
+    bool pairDefer_ = true;          // false after the same eye came twice in a row, until the other eye is seen again
+    int lastEye_ = -1;
+    bool lastApplyRecorded_ = false; // the last Apply only recorded its submission (ovrfsr_pair_pending)
     ovrfsr_image pendingIn_{}, pendingOut_{};
+    void *retired_ = nullptr; // a ctx-owned output image a flushed pair_submit eye was handed in, kept across the rebuild of a size change
+    void ResetKeeping(bool keepRetired);
     int FlushPending(hipStream_t stream);
     bool OverlapOutside(const ovrfsr_image &in) const; // does a masked pass run its outside-tile kernel on the auxiliary stream?
     hipStream_t Fork(hipStream_t user, bool overlap);

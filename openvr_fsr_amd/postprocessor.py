@@ -101,6 +101,10 @@ class PostProcessor:
                                                  outs.stride(0) * outs.element_size(), self._stream()))
         return outs
 
+    def pair_pending(self):
+        """cfg.pair_submit: did the last apply only record its submission (ovrfsr_pair_pending)?"""
+        return bool(self._lib.ovrfsr_pair_pending(self._ctx))
+
     def last_gpu_time_ms(self):
         ms = C.c_float()
         self._check(self._lib.ovrfsr_last_gpu_time_ms(self._ctx, C.byref(ms)))

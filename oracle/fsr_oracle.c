@@ -116,6 +116,16 @@ OVO_API float ovo_rcas_stops_from_sharpness(float sharpness)
     return 2.f - 2 * s;
 }
 
+/* float -> uint32: the reference's `(uint32_t)x` where that is defined (0 <= x < 2^32), total elsewhere (NaN / negative -> 0,
+ * >= 2^32 -> 0xffffffff): the C cast is undefined behaviour outside the range, and the checker must not depend on the host compiler's
+ * choice there.  The product converts the same way (csrc/constants.cpp f2u_sat); for every in-range value the known answers hold. */
+static uint32_t f2u_sat(float x)
+{
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)x;
+}
+
 /* postprocess/PostProcessor.cpp:298-305 (shared / first-eye buffer) and :331-335 (right-eye
  * buffer when each eye has its own texture).  proj = {Lx, Ly, Rx, Ry} in [0,1].
  * Every store is float -> uint32 truncation; radius[1] is a uint32 multiply. */
@@ -124,17 +134,17 @@ OVO_API void ovo_mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t
                                 int eye)
 {
     if (textureContainsOnlyOneEye && eye == 1) {
-        centre[0] = (uint32_t)(outW * proj[2]);
-        centre[1] = (uint32_t)(outH * proj[3]);
-        centre[2] = (uint32_t)(outW * proj[2]);
-        centre[3] = (uint32_t)(outH * proj[3]);
+        centre[0] = f2u_sat(outW * proj[2]);
+        centre[1] = f2u_sat(outH * proj[3]);
+        centre[2] = f2u_sat(outW * proj[2]);
+        centre[3] = f2u_sat(outH * proj[3]);
     } else {
-        centre[0] = (uint32_t)(textureContainsOnlyOneEye ? outW * proj[0] : outW / 2 * proj[0]);
-        centre[1] = (uint32_t)(outH * proj[1]);
-        centre[2] = (uint32_t)(textureContainsOnlyOneEye ? outW * proj[0] : outW / 2 * (1 + proj[2]));
-        centre[3] = (uint32_t)(outH * (textureContainsOnlyOneEye ? proj[1] : proj[3]));
+        centre[0] = f2u_sat(textureContainsOnlyOneEye ? outW * proj[0] : outW / 2 * proj[0]);
+        centre[1] = f2u_sat(outH * proj[1]);
+        centre[2] = f2u_sat(textureContainsOnlyOneEye ? outW * proj[0] : outW / 2 * (1 + proj[2]));
+        centre[3] = f2u_sat(outH * (textureContainsOnlyOneEye ? proj[1] : proj[3]));
     }
-    radius[0] = (uint32_t)(0.5f * cfgRadius * outH);
+    radius[0] = f2u_sat(0.5f * cfgRadius * outH);
     radius[1] = radius[0] * radius[0];
     radius[2] = outW;
     radius[3] = outH;

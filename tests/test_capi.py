@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_abi_version_and_struct_sizes():
     L = A.library()
-    assert L.ovrfsr_abi_version() == 4
+    assert L.ovrfsr_abi_version() == 5
     cfg = A.Config.default()
     assert cfg.struct_size == C.sizeof(A.Config) == 80
     assert C.sizeof(A.Image) == 24 and C.sizeof(A.Bounds) == 16
@@ -88,6 +88,91 @@ def test_create_rejects_configurations_no_kernel_exists_for():
     assert not hasattr(A, "PRECISION_FP16")
     hdr = open(os.path.join(ROOT, "include", "openvr_fsr_amd.h")).read()
     assert "OVRFSR_PRECISION_FP16" not in hdr.split("typedef enum ovrfsr_precision")[1].split("}")[0]
+
+
+@pytest.mark.parametrize("kw", [dict(radius=-1.0), dict(radius=float("nan")), dict(radius=float("inf")), dict(radius=-0.001),
+                                dict(proj_centre=(float("nan"), 0.5, 0.5, 0.5)), dict(proj_centre=(0.5, -1.5, 0.5, 0.5)), dict(proj_centre=(0.5, 0.5, 1e9, 0.5)),
+                                dict(proj_centre=(0.5, 0.5, 0.5, float("inf"))), dict(sharpness=float("nan")), dict(sharpness=float("-inf")),
+                                dict(render_scale=float("nan"))])
+def test_create_rejects_values_the_mask_conversion_is_undefined_for(kw):
+    """Round 6: radius / proj_centre feed float -> uint32 conversions (PostProcessor.cpp:298-305) that are undefined
+    behaviour for NaN, negative or huge values; the reference validates nothing (Config.h:36-45 clamps a negative sharpness only).  A ctx
+    is never built around such a value, and set_config keeps the old configuration."""
+    ctx = C.c_void_p()
+    cfg = A.Config.default(fsr_enabled=1, **kw)
+    assert A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx)) == 1 and not ctx
+
+
+@pytest.mark.parametrize("kw", [dict(radius=0.0), dict(radius=1e9), dict(radius=2.0), dict(proj_centre=(-0.5, -1.0, 2.0, 1.5)), dict(sharpness=-3.0),
+                                dict(sharpness=7.0)])
+def test_create_accepts_every_value_with_a_defined_meaning(kw):
+    """... and nothing more is refused than that: radius 0 (everything outside), a huge finite radius (the conversion saturates), centres
+    off the image (clamped to 0 by the conversion), any finite sharpness (clamped to [0,1] like the reference's AClampF1): create gets past the
+    validation -- without a GPU it then reports NO_DEVICE, never INVALID_ARGUMENT."""
+    import torch
+    ctx = C.c_void_p()
+    cfg = A.Config.default(fsr_enabled=1, **kw)
+    rc = A.library().ovrfsr_create(0, C.byref(cfg), C.byref(ctx))
+    assert rc == (0 if torch.cuda.is_available() else 4), rc
+    if ctx:
+        A.library().ovrfsr_destroy(ctx)
+
+
+def test_mask_constants_is_total_and_keeps_the_known_answers():
+    """ovrfsr_mask_constants on the probes of VERDICT r5 (radius -1 / NaN / 1e9, proj NaN / -0.5 / 1e9): saturating conversion -- NaN and
+    negatives give 0, >= 2^32 gives 0xffffffff -- the same in the product and in the oracle; in-range values keep SURVEY.md 8c's answers."""
+    from oracle import oracle as O
+    half = (0.5, 0.5, 0.5, 0.5)
+    # known answers (SURVEY 8c): radius 0.5 -> 623 @2492, 790 @3160
+    c, r = A.mask_constants(2244, 2492, half, 0.5, True, 0)
+    assert list(c) == [1122, 1246, 1122, 1246] and list(r) == [623, 388129, 2244, 2492]
+    c, r = A.mask_constants(3160, 3160, half, 0.5, True, 1)
+    assert list(r) == [790, 624100, 3160, 3160]
+    probes = [(-1.0, half), (float("nan"), half), (1e9, half), (float("inf"), half), (0.5, (float("nan"), 0.5, 0.5, 0.5)),
+              (0.5, (-0.5, 0.5, -0.5, 0.5)), (0.5, (1e9, 0.5, 1e9, 0.5)), (0.5, (float("-inf"), float("inf"), 0.5, 0.5)), (-0.0, half), (1e30, half)]
+    for radius, proj in probes:
+        for one_eye in (True, False):
+            for eye in (0, 1):
+                c, r = A.mask_constants(2244, 2492, proj, radius, one_eye, eye)
+                co, ro = O.mask_constants(2244, 2492, radius, proj, one_eye, eye)
+                assert list(c) == list(co) and list(r) == list(ro), (radius, proj, one_eye, eye)
+    c, r = A.mask_constants(2244, 2492, half, -1.0, True, 0)
+    assert r[0] == 0 and r[1] == 0
+    c, r = A.mask_constants(2244, 2492, half, float("nan"), True, 0)
+    assert r[0] == 0
+    c, r = A.mask_constants(2244, 2492, half, 1e9, True, 0)
+    assert r[0] == 0xffffffff and r[1] == 1                      # uint32 wrap of r * r, as the reference's multiply
+    c, r = A.mask_constants(2244, 2492, (float("nan"), -0.5, 1e9, 0.5), 0.5, True, 0)
+    assert list(c) == [0, 0, 0, 0]
+    c, r = A.mask_constants(2244, 2492, (float("nan"), -0.5, 1e9, 0.5), 0.5, True, 1)
+    assert list(c) == [0xffffffff, 1246, 0xffffffff, 1246]
+
+
+def test_config_file_never_yields_a_cfg_that_create_refuses():
+    """ovrfsr_config_from_json: a negative radius is clamped to 0 (the reference's rule for sharpness, Config.h:40), a number that
+    overflows float is a read error (defaults); what it returns always passes create's validation."""
+    rc, cfg = A.config_from_json('{"fsr": {"enabled": true, "radius": -1, "sharpness": -2}}')
+    assert rc == 0 and cfg.radius == 0.0 and cfg.sharpness == 0.0 and cfg.fsr_enabled == 1
+    for text in ('{"fsr": {"enabled": true, "radius": 1e999}}', '{"fsr": {"sharpness": 1e999}}', '{"fsr": {"enabled": true, "renderScale": 1e400}}'):
+        rc, cfg = A.config_from_json(text)
+        assert rc == 1 and cfg.fsr_enabled == 0 and cfg.radius == 0.5 and cfg.sharpness == 0.75 and cfg.render_scale == 1.0, text
+    rc, cfg = A.config_from_json('{"fsr": {"sharpness": -1e999}}')   # -inf < 0: clamped to 0 by the reference's own rule
+    assert rc == 0 and cfg.sharpness == 0.0
+
+
+def test_capture_writers_validate_the_image_before_touching_it(tmp_path):
+    """ovrfsr_save_ppm / ovrfsr_save_dds apply the rules ovrfsr_apply puts on caller images (size, pitch >= width * texel, alignment) before
+    anything is copied: a too-small pitch used to make the row loop read past the host copy.  No device is touched."""
+    L = A.library()
+    path = str(tmp_path / "x.bin").encode()
+    fake = 0x7f0000001000   # never dereferenced: every case is refused first
+    bad = [K.Image(fake, 64, 8, 64 * 4 - 4, K.FORMAT_RGBA8), K.Image(fake, 64, 8, 64 * 8 - 8, K.FORMAT_RGBA16F), K.Image(fake, 0, 8, 256, K.FORMAT_RGBA8),
+           K.Image(fake, 64, 0, 256, K.FORMAT_RGBA8), K.Image(fake, 16385, 8, 16385 * 4, K.FORMAT_RGBA8), K.Image(fake, 8, 16385, 32, K.FORMAT_RGBA8),
+           K.Image(fake + 2, 64, 8, 256, K.FORMAT_RGBA8), K.Image(fake, 64, 8, 258, K.FORMAT_RGBA8), K.Image(fake, 64, 8, 256, 9), K.Image(0, 64, 8, 256, K.FORMAT_RGBA8)]
+    for img in bad:
+        assert L.ovrfsr_save_dds(C.byref(img), path, None) == 1
+        assert L.ovrfsr_save_ppm(C.byref(img), path, None) == 1
+    assert not os.path.exists(path.decode())
 
 
 def test_null_ctx_is_an_error_not_a_crash():

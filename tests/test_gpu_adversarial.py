@@ -92,11 +92,9 @@ def test_audit_build_finds_no_flip():
     import re
     import subprocess
     import sys
-    lib = os.path.join(ROOT, "ab", "audit.so")
-    # (re)build through make: a no-op when ab/audit.so is newer than every source, 40 s otherwise -- an audit of stale kernels proves nothing
-    r = subprocess.run([os.path.join(ROOT, "tools", "build_variant.sh"), "audit", "-DOVRFSR_TIE_AUDIT"], capture_output=True, text=True, timeout=900)
-    if r.returncode != 0 or not os.path.exists(lib):
-        pytest.skip("audit build unavailable here: " + (r.stderr or r.stdout)[-300:])
+    from tests.variants import variant
+    # a FRESH audit build (hash stamp of the sources it was built from; rebuilt here when stale) -- an audit of stale kernels proves nothing
+    lib = variant("audit", "-DOVRFSR_TIE_AUDIT")
     env = dict(os.environ, OVRFSR_LIB=lib, PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "tie_audit.py"), "0.17"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     m = re.search(r"TOTAL audited (\d+) pixels, listed (\d+) .*?FLIPS (\d+)", r.stdout)

@@ -276,6 +276,75 @@ def test_pair_submit_is_the_same_pixels_in_two_launches(name, cfg, dt):
             pp.close()
 
 
+@pytest.mark.parametrize("name,cfg,dt", PAIR_CASES, ids=[c[0] for c in PAIR_CASES])
+def test_pair_submit_pairs_by_arrival_order(name, cfg, dt):
+    """Round 6: a game that submits R, L, R, L ...  The first eye of a frame is recorded whichever it is, the other eye
+    launches both: after the second call of frame f BOTH results of frame f are there (in stream order) -- until round 6 only LEFT was
+    recorded, so LEFT(f) was batched with RIGHT(f + 1) and its output stayed unwritten for a whole frame.  Caller-owned outputs laid out either
+    way round relative to the inputs (the strides of the batch of two are differences modulo 2^64), and ctx-owned ones."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh, frames = 480, 405, 640, 540, 5
+    tdt = {np.uint8: torch.uint8, np.float16: torch.float16}[dt]
+    src = _batch(dt, 11, 4, iw, ih)
+    plain = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **cfg)
+    ref = [plain.apply(i & 1, src[i], out_dtype=tdt).clone() for i in range(4)]
+    torch.cuda.synchronize()
+    plain.close()
+    for layout in ("outputs like inputs", "outputs reversed", "ctx-owned"):
+        pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, pair_submit=1, **cfg)
+        try:
+            res = []
+            for f in range(frames):
+                a = 2 * (f & 1)
+                outs = torch.zeros((2, oh, ow, 4), dtype=tdt, device="cuda")
+                lo, ro = (0, 1) if layout == "outputs like inputs" else (1, 0)
+                if layout == "ctx-owned":
+                    o_r = pp.apply(A.EYE_RIGHT, src[a + 1])          # recorded: nothing launched yet
+                    o_l = pp.apply(A.EYE_LEFT, src[a])               # both eyes, one batch of two
+                    assert o_r.data_ptr() != o_l.data_ptr()
+                    res.append((a, o_l.clone(), o_r.clone()))
+                else:
+                    o_r = pp.apply(A.EYE_RIGHT, src[a + 1], out=outs[ro])
+                    assert o_r.data_ptr() == outs[ro].data_ptr()
+                    pp.apply(A.EYE_LEFT, src[a], out=outs[lo])
+                    res.append((a, outs[lo].clone(), outs[ro].clone()))  # a consumer right behind the second call of the SAME frame
+            torch.cuda.current_stream().synchronize()
+            for k, (a, gl, gr) in enumerate(res):
+                assert torch.equal(gl.view(torch.uint8), ref[a].view(torch.uint8)), "%s, %s: left eye of frame %d differs" % (name, layout, k)
+                assert torch.equal(gr.view(torch.uint8), ref[a + 1].view(torch.uint8)), "%s, %s: right eye of frame %d differs" % (name, layout, k)
+        finally:
+            pp.close()
+
+
+def test_pair_submit_ctx_owned_image_survives_a_size_change():
+    """a recorded eye with a ctx-owned output, then a submission of another size: the recorded eye is processed with the old
+    resources and the rebuild must not free the image its result went to (the caller was handed that pointer)."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih = 320, 270
+    src = _batch(np.uint8, 13, 2, iw, ih)
+    small = _batch(np.uint8, 14, 1, 160, 120)
+    kw = dict(fsr_enabled=1, render_scale=0.75, precision=FP32, radius=0.6, sharpness=0.8)
+    plain = A.PostProcessor(**kw)
+    ref = plain.apply(0, src[0], out_dtype=torch.uint8).clone()
+    ref_small = plain.apply(1, small[0], out_dtype=torch.uint8).clone()
+    torch.cuda.synchronize()
+    plain.close()
+    pp = A.PostProcessor(pair_submit=1, **kw)
+    try:
+        o_l = pp.apply(0, src[0])                    # recorded, ctx-owned destination
+        o_r = pp.apply(1, small[0])                  # another size: LEFT flushed with the old resources, ctx rebuilt, this eye recorded
+        junk = [torch.full((427 * 360 * 4,), 77, dtype=torch.uint8, device="cuda") for _ in range(8)]   # would reuse a freed block
+        o_l2 = pp.apply(0, small[0])                 # pairs with the recorded small RIGHT
+        torch.cuda.synchronize()
+        assert torch.equal(o_l, ref), "the left image was freed or overwritten by the rebuild"
+        assert torch.equal(o_r, ref_small) and o_l2.shape == o_r.shape
+        del junk
+    finally:
+        pp.close()
+
+
 def test_pair_submit_falls_back_to_single_launches():
     """A LEFT that no matching RIGHT follows is processed on its own by the next call: two LEFTs in a row, outputs laid out the other way round
     than the inputs, a texture of another size, ovrfsr_apply_batch in between, ctx-owned outputs (two images in this mode); reset drops it."""
@@ -291,21 +360,37 @@ def test_pair_submit_falls_back_to_single_launches():
     pp = A.PostProcessor(pair_submit=1, **kw)
     try:
         outs = torch.zeros((4, oh, ow, 4), dtype=torch.uint8, device="cuda")
-        # LEFT, LEFT, RIGHT: the first LEFT is flushed by the second; the second pairs with the RIGHT
-        pp.apply(0, src[0], out=outs[0]); pp.apply(0, src[2], out=outs[2]); pp.apply(1, src[3], out=outs[3])
+        # LEFT, LEFT, RIGHT: the first LEFT is flushed by the second, which is processed at once too (the same eye twice stops the recording
+        # until the other eye is seen: a one-eye-per-frame host must not see every result a call late); the RIGHT is then processed at once
+        pp.apply(0, src[0], out=outs[0]); assert pp.pair_pending()
+        pp.apply(0, src[2], out=outs[2]); assert not pp.pair_pending()
         torch.cuda.synchronize()
-        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[2], ref[2]) and torch.equal(outs[3], ref[3])
-        # outputs ordered against the inputs: two single launches, same pixels
+        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[2], ref[2])
+        pp.apply(0, src[0], out=outs[1]); assert not pp.pair_pending()      # still one eye only: immediate
+        pp.apply(1, src[3], out=outs[3]); assert not pp.pair_pending()      # the other eye is back: immediate, pairing resumes with the next call
+        torch.cuda.synchronize()
+        assert torch.equal(outs[1], ref[0]) and torch.equal(outs[3], ref[3])
+        pp.apply(0, src[0], out=outs[0]); assert pp.pair_pending()
+        pp.apply(1, src[1], out=outs[1]); assert not pp.pair_pending()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1])
+        # outputs ordered against the inputs: still one batch of two since round 6 (strides modulo 2^64), same pixels
         outs.zero_()
         pp.apply(0, src[0], out=outs[1]); pp.apply(1, src[1], out=outs[0])
         torch.cuda.synchronize()
         assert torch.equal(outs[1], ref[0]) and torch.equal(outs[0], ref[1])
-        # a batch call between LEFT and RIGHT: the LEFT goes first, the RIGHT is then a single apply
+        # a batch call between LEFT and RIGHT: the LEFT goes first; the RIGHT -- a frame's SECOND eye (order learned from the pairs above) that
+        # finds nothing recorded -- is a single apply at once, and the next frame pairs again (no standing lag)
         outs.zero_()
         b = torch.zeros((2, oh, ow, 4), dtype=torch.uint8, device="cuda")
-        pp.apply(0, src[0], out=outs[0]); pp.apply_batch(src[2:4], b); pp.apply(1, src[1], out=outs[1])
+        pp.apply(0, src[0], out=outs[0]); pp.apply_batch(src[2:4], b); assert not pp.pair_pending()
+        pp.apply(1, src[1], out=outs[1]); assert not pp.pair_pending()
         torch.cuda.synchronize()
         assert torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1]) and torch.equal(b[0], ref[2]) and torch.equal(b[1], ref[3])
+        pp.apply(0, src[2], out=outs[2]); assert pp.pair_pending()
+        pp.apply(1, src[3], out=outs[3]); assert not pp.pair_pending()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[2], ref[2]) and torch.equal(outs[3], ref[3])
         # ctx-owned outputs: two distinct images, both valid after the RIGHT call
         o_l = pp.apply(0, src[2]); o_r = pp.apply(1, src[3])
         torch.cuda.synchronize()

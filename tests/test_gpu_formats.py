@@ -224,14 +224,26 @@ def _hdr_image(iw, ih, seed, scale, kind):
 
 
 @pytest.mark.parametrize("scale,kind", [(1.0, "scaled"), (6.0, "scaled"), (40.0, "scaled"), (6.0, "highlights"), (40.0, "highlights"), (400.0, "highlights")])
-def test_half_intermediate_is_the_strict_builds_also_on_hdr(gpu, scale, kind, monkeypatch):
+def test_half_intermediate_is_the_strict_builds_also_on_hdr(gpu, scale, kind):
     """Round 5 (VERDICT r4 Next #5): the HALF near-tie guard scales its band with the largest texel of the tile's footprint, so the
-    product build's half intermediate equals the strict build's BIT FOR BIT for every channel >= xmin on HDR content too -- read here
+    product kernels' half intermediate equals the strict build's BIT FOR BIT for every channel >= xmin on HDR content too -- read here
     as the output of an EASU-only RGBA16F pass with the guard forced on from 0.5 (OVRFSR_TIE_HALF_MIN, the value the sharpness-0.9
     pipeline uses).  Channels below xmin are outside the guard's contract (a flipped half-ulp there stays under 1e-3 behind RCAS's
-    largest gain): they may differ by one half-ulp, no more."""
+    largest gain): they may differ by one half-ulp, no more.
+    Round 6: the shipped library no longer reads that environment variable -- only audit builds do (the same kernels plus the
+    re-resolve that counts flips; what they STORE is the product's) -- so the body runs in a subprocess against ab/audit.so."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("OVRFSR_HALF_GUARD_INNER") != "1":
+        from tests.variants import ROOT, variant
+        lib = variant("audit", "-DOVRFSR_TIE_AUDIT")
+        env = dict(os.environ, OVRFSR_LIB=lib, OVRFSR_TIE_HALF_MIN="0.5", OVRFSR_HALF_GUARD_INNER="1", PYTHONPATH=ROOT)
+        node = "%s::test_half_intermediate_is_the_strict_builds_also_on_hdr[%s-%s]" % (os.path.abspath(__file__), scale, kind)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "gpu", node], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0 and "1 passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+        return
     from tests.util import run_gpu
-    monkeypatch.setenv("OVRFSR_TIE_HALF_MIN", "0.5")
     iw, ih, ow, oh = 474, 360, 632, 480
     for seed in (5, 6):
         imgh = _hdr_image(iw, ih, seed, scale, kind)
