@@ -83,6 +83,35 @@ def random_batch(n_img, w, h, dtype, device, base_seed):
     return out
 
 
+_NATURAL = {}
+
+
+def natural_batch(n_img, w, h, dtype, device, base_seed):
+    """NATURAL content (round 6): the three 256x256 fixtures of tests/golden/natural_*.npz -- rendered game art, a rendered UI with text, a
+    photograph (provenance: tests/golden/make_natural.py) -- mirror-tiled to the eye size on the consuming GPU, image i from fixture
+    (seed + i) % 3 at a seed-dependent offset (the same tiling as tests/natural.py)."""
+    if device not in _NATURAL:
+        gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+        _NATURAL[device] = [torch.from_numpy(np.load(os.path.join(gold, "natural_%s.npz" % k))["rgba8"]).to(device) for k in ("cube", "portal", "hopper")]
+    out = torch.empty((n_img, h, w, 4), dtype=dtype, device=device)
+    for i in range(n_img):
+        seed = (base_seed + i) & 0xffff
+        src = _NATURAL[device][seed % 3]
+        n = src.shape[0]
+
+        def index(length, off):
+            j = (torch.arange(length, device=device) + off) % (2 * n)
+            return torch.where(j < n, j, 2 * n - 1 - j)
+
+        img = src[index(h, (seed * 101) % n)][:, index(w, (seed * 37) % n)]
+        if dtype == torch.uint8:
+            out[i] = img
+        else:
+            out[i] = (img.float() / 255.0).to(dtype)
+            out[i, ..., 3] = 1.0
+    return out
+
+
 def synth_batch(n_img, w, h, dtype, device, base_seed):
     """Structured synthetic eye images generated ON the consuming GPU: sinusoid gradients,
     hard 45/135-degree edges, +-4/255 noise, a constant block; alpha = 1."""
@@ -448,6 +477,10 @@ def dominant_kernels(workload):
     return ["easu_fast_kernel"]
 
 
+# datasheet issue cycles per wave64 VALU instruction on a SIMD32 (MI355X_MICROARCH.md: "issues each VALU instruction over 2 cycles"; packed,
+# conversion, min/max/med3, 3-operand integer and DPP forms at half rate; transcendentals at quarter rate)
+DATASHEET_COST = {"fast": 2.0, "slow": 4.0, "pk": 4.0, "trans": 8.0}
+
 PMC_PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"],
               # instruction counts per category and waves: what tools/isa_costs.py turns into VALU issue cycles (roofline.valu.issue)
               ["SQ_WAVES", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_BRANCH", "SQ_INSTS_VALU_TRANS_F32"]]
@@ -533,7 +566,7 @@ def issue_roof(pmc, kernels, scale, out_px, ms_dom, sclk_mhz):
         doc = isa_costs.load()
     except (OSError, ValueError, ImportError) as e:
         return {"error": "no issue-cost table (%s): run __graft_entry__.build()" % e}
-    per_kernel, lo_sum, hi_sum = {}, 0.0, 0.0
+    per_kernel, lo_sum, hi_sum, ds_lo, ds_hi = {}, 0.0, 0.0, 0.0, 0.0
     for k in kernels:
         v = pmc.get(k)
         full = sorted(PMC_FULL_NAMES.get(k, ()))
@@ -557,6 +590,12 @@ def issue_roof(pmc, kernels, scale, out_px, ms_dom, sclk_mhz):
         waves = w * scale
         lo_sum += b["lo"] * waves
         hi_sum += b["hi"] * waves
+        # the same execution profiles priced at DATASHEET issue costs (MI355X_MICROARCH.md, execution model: a wave64 VALU instruction
+        # issues over 2 cycles on its SIMD32; packed / conversion / 3-operand / DPP forms over 4; transcendentals over 8): model-free
+        d = isa_costs.issue_bounds(cfg, pw, cost=DATASHEET_COST)
+        if d is not None:
+            ds_lo += d["lo"] * waves
+            ds_hi += d["hi"] * waves
         per_kernel[k] = {"kernel": full[0], "waves_per_launch": int(waves), "valu_instr_per_wave": round(pw["valu"], 1),
                          "per_wave_counters": {a: round(x, 4) for a, x in pw.items()},
                          "issue_cycles_per_wave": [round(b["lo"], 1), round(b["hi"], 1)], "mean_cycles_per_valu_instr": [round(b["mean_cost_lo"], 3), round(b["mean_cost_hi"], 3)],
@@ -572,11 +611,17 @@ def issue_roof(pmc, kernels, scale, out_px, ms_dom, sclk_mhz):
     if sclk_mhz:
         cap = 1024.0 * sclk_mhz * 1e6 * ms_dom * 1e-3   # SIMD-cycles available in the launch
         out["issue_frac"] = [round(lo_sum / cap, 3), round(hi_sum / cap, 3)]
+        if ds_hi > 0.0:
+            out["datasheet_issue_frac"] = [round(ds_lo / cap, 3), round(ds_hi / cap, 3)]
+            out["datasheet_costs_cycles"] = DATASHEET_COST
     return out
 
 
-def roofline(args, shard):
-    """The dominant kernel against the HBM roof the contract names, and against the roof that binds it (VALU issue)."""
+def roofline(args, shard, timed_ms_step=None):
+    """The dominant kernel against the HBM roof the contract names, and against the roof that binds it (VALU issue).
+    timed_ms_step: HIP-event milliseconds per step of shard 0 INSIDE the timed region (GpuShard.mark_start / mark_end bracket exactly the
+    `steps` timed calls): the pipeline figure of the line is that one, so it can never exceed the wall-clock ms_per_step it sits beside
+    (round 5 re-timed the step in a later pass, which read 1.5 % more than the timed loop on a different clock state)."""
     A = shard.A
     inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
     dev, n_img = shard.dev, shard.n_img
@@ -584,7 +629,7 @@ def roofline(args, shard):
     algo_bytes_eye = bpp * (inW * inH + outW * outH)  # pipeline compulsory traffic per eye
     stream = torch.cuda.current_stream(dev)
     iters = max(5, args.steps // 2)
-    ms_step = time_events(shard.step, iters, stream)
+    ms_step = timed_ms_step if timed_ms_step else time_events(shard.step, iters, stream)
     kernels = dominant_kernels(args.workload)
     single_pass = len(kernels) > 1 or use_nis or (inW, inH) == (outW, outH)
     sclk = SclkSampler(shard.device_index)   # shader clock while the dominant kernel runs (valu.issue_frac needs cycles, not nominal GHz)
@@ -612,9 +657,15 @@ def roofline(args, shard):
             "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
             "launch_ms": round(ms_dom, 4), "algorithmic_bytes_per_launch": dom_bytes,
             "copy_ceiling": round(copy_gbps, 1), "frac_of_copy": round(ach / copy_gbps, 4),
-            "pipeline_ms_per_step_events": round(ms_step, 4), "pipeline_achieved_GBps": round(pipe, 1),
+            "pipeline_ms_per_step_events": round(ms_step, 4),
+            "pipeline_events_source": "HIP events around the timed loop itself (shard 0)" if timed_ms_step else "a separate event-timed pass",
+            "pipeline_achieved_GBps": round(pipe, 1),
             "pipeline_frac": round(pipe / HBM_PEAK_GBPS, 4), "binding_roof": "valu_issue", "valu": None,
-            "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_source": sclk.source, "sclk_samples": len(sclk.samples)}
+            "sclk_mhz": round(sclk_mhz, 1) if sclk_mhz else None, "sclk_source": sclk.source, "sclk_samples": len(sclk.samples),
+            # socket power while the dominant kernel ran, and the cap it runs under: for a VALU-issue-bound kernel the clock IS the roof, and
+            # the clock is what the power cap leaves (a reader can tell a capped 2.1 GHz from a quiet 2.4 GHz box)
+            "power_w": round(sclk.mean_power_w(), 1) if sclk.mean_power_w() else None, "power_cap_w": sclk.power_cap_w,
+            "power_source": sclk.power_source}
     pmc = pmc_counters(args) if args.pmc == "auto" else None
     if pmc:
         child_img = images_per_pair(args.workload) * PMC_CHILD_PAIRS
@@ -651,6 +702,8 @@ def roofline(args, shard):
             issue = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
         if "error" not in issue:
             roof["valu"]["issue"] = issue
+            if issue.get("datasheet_issue_frac") is not None:
+                roof["valu"]["datasheet_issue_frac"] = issue["datasheet_issue_frac"]
         else:
             roof["valu"]["issue_unavailable"] = issue["error"]
     if roof["traffic"] is None:
@@ -669,7 +722,9 @@ class SclkSampler:
 
     def __init__(self, device_index, period_s=0.004):
         self.idx, self.period, self.samples, self._stop, self._thr = device_index, period_s, [], False, None
+        self.power_samples, self.power_cap_w, self.power_source, self._read_power = [], None, None, None
         self._read = self._probe()
+        self._probe_power()
 
     def _probe(self):
         try:
@@ -707,14 +762,59 @@ class SclkSampler:
         self.source = None
         return None
 
+    def _probe_power(self):
+        """socket power (W) and its cap: amdsmi where it is importable, else the hwmon nodes of the device"""
+        def watts(v):
+            return None if not isinstance(v, (int, float)) or v <= 0 else (float(v) * 1e-6 if v > 20000 else float(v))   # microwatts or watts
+        try:
+            import amdsmi
+            h = amdsmi.amdsmi_get_processor_handles()[self.idx]
+
+            def read():
+                info = amdsmi.amdsmi_get_power_info(h)
+                return watts(info.get("current_socket_power")) or watts(info.get("average_socket_power")) or watts(info.get("socket_power"))
+            if read() is not None:
+                self._read_power, self.power_source = read, "amdsmi_get_power_info(socket power)"
+                try:
+                    cap = amdsmi.amdsmi_get_power_cap_info(h)
+                    self.power_cap_w = watts(cap.get("power_cap")) or watts(amdsmi.amdsmi_get_power_info(h).get("power_limit"))
+                except Exception:  # noqa: BLE001
+                    self.power_cap_w = watts(amdsmi.amdsmi_get_power_info(h).get("power_limit"))
+                return
+        except Exception:  # noqa: BLE001
+            pass
+        try:
+            import glob
+            cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+            base = cards[min(self.idx, len(cards) - 1)]
+            nodes = glob.glob(base + "/hwmon/hwmon*/power1_average") + glob.glob(base + "/hwmon/hwmon*/power1_input")
+            node = nodes[0]
+
+            def read_sysfs():
+                return watts(int(open(node).read().strip()))
+            if read_sysfs() is not None:
+                self._read_power, self.power_source = read_sysfs, node
+                try:
+                    self.power_cap_w = watts(int(open(os.path.join(os.path.dirname(node), "power1_cap")).read().strip()))
+                except (OSError, ValueError):
+                    pass
+        except Exception:  # noqa: BLE001
+            pass
+
+    def mean_power_w(self):
+        return sum(self.power_samples) / len(self.power_samples) if self.power_samples else None
+
     def __enter__(self):
-        if self._read:
+        if self._read or self._read_power:
             def loop():
                 while not self._stop:
                     try:
-                        v = self._read()
+                        v = self._read() if self._read else None
                         if v:
                             self.samples.append(v)
+                        p = self._read_power() if self._read_power else None
+                        if p:
+                            self.power_samples.append(p)
                     except Exception:  # noqa: BLE001
                         pass
                     time.sleep(self.period)
@@ -746,6 +846,25 @@ def content_random_leg(args, shard, steps):
         ok = (r["n_diff"] == 0) if args.precision == "strict" else (r["max_lsb"] <= 1 if "max_lsb" in r else r["n_gt_1e3"] == 0 and r["n_nan"] == 0)
         return {"content": "uniform random texels", "value": round(args.pairs / (ms * 1e-3), 2), "unit": "eye-pairs/s", "ms_per_step": round(ms, 4),
                 "parity_image0": dict(r, ok=bool(ok))}
+    finally:
+        shard.texs = keep
+
+
+def content_natural_leg(args, shard, steps):
+    """The same workload and launch on NATURAL content (natural_batch): real edges, text, photographic noise -- what the guard's listed-pixel
+    rate, EASU's dering clamp and NVScaler's edge classification see in use -- un-timed for the headline, reported beside it.  Image 0 of
+    that batch is checked against the oracle as well."""
+    inW, inH, outW, outH, dtype, radius, use_nis = WORKLOADS[args.workload]
+    keep = shard.texs
+    stream = torch.cuda.current_stream(shard.dev)
+    try:
+        shard.texs = natural_batch(shard.n_img, inW, inH, dtype, shard.dev, shard_seed(args.pairs, shard.shard_index))
+        ms = time_events(shard.step, max(5, steps), stream)
+        (src, got), = shard.fetch([0])
+        r = compare_images(got, oracle_expected(args.workload, src, 0))
+        ok = (r["n_diff"] == 0) if args.precision == "strict" else (r["max_lsb"] <= 1 if "max_lsb" in r else r["n_gt_1e3"] == 0 and r["n_nan"] == 0)
+        return {"content": "natural (tests/golden/natural_*.npz, mirror-tiled)", "value": round(args.pairs / (ms * 1e-3), 2), "unit": "eye-pairs/s",
+                "ms_per_step": round(ms, 4), "parity_image0": dict(r, ok=bool(ok))}
     finally:
         shard.texs = keep
 
@@ -849,7 +968,7 @@ def parse_args(argv=None):
     ap.add_argument("--oversubscribe", action="store_true",
                     help="testing only: map shard i to device i %% device_count (exercise the N>1 launchers on a box with fewer GPUs)")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed call's outputs (parity_check)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the un-timed extra legs (content_random, frame)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the un-timed extra legs (content_random, content_natural, frame)")
     ap.add_argument("--content", default="structured", choices=["structured", "random"],
                     help="synthetic eye content: structured (gradients+edges+noise, default) or uniform random")
     return ap.parse_args(argv)
@@ -924,6 +1043,7 @@ def main(argv=None):
 
     dt_local, dev_ms = run_local(shards, args.steps, args.warmup, 0.0 if mock else CLOCK_RAMP_S, cross)
     dt = max_over_ranks(dt_local, world)
+    dev_ms_local0 = dev_ms[0] if dev_ms else None   # shard 0 of THIS process: HIP events around exactly the timed steps
     dev_ms = gather_over_ranks(dev_ms, world)   # one entry per GPU of the job, whatever the launcher
     # every shard checks image 0 of its own timed batch against the oracle (collective: every rank contributes its records)
     per_shard = None if args.no_verify else gather_over_ranks([shard_parity(args, s) for s in shards], world)
@@ -938,7 +1058,7 @@ def main(argv=None):
         # the outputs of the TIMED launches, before anything else writes the output batch
         indices = check_indices(images_per_pair(args.workload) * args.pairs)
         fetched = None if (args.no_verify or mock) else shards[0].fetch(indices)
-        roof = None if mock else roofline(args, shards[0])
+        roof = None if mock else roofline(args, shards[0], timed_ms_step=(dev_ms_local0 / args.steps) if dev_ms_local0 else None)
         if n_gpus == 1 and not args.no_extras and not mock:
             def leg(fn, *a):   # un-timed extra legs run before the line is printed: a failure in one must not lose the headline
                 try:
@@ -947,6 +1067,7 @@ def main(argv=None):
                     return {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
             if args.content == "structured":
                 extras["content_random"] = leg(content_random_leg, args, shards[0], args.steps // 2)
+                extras["content_natural"] = leg(content_natural_leg, args, shards[0], args.steps // 2)
             extras["frame"] = leg(frame_leg, args, shards[0])
         if fetched is not None:
             par, cpu = parity_and_cpu(args, fetched, indices, want_cpu=(n_gpus == 1 and not args.no_cpu))   # CPU baseline: N=1 only

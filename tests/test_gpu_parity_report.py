@@ -4,7 +4,9 @@ Each case runs the HIP path through the C ABI and the CPU oracle on the same see
   max_abs   largest |difference| on float outputs (unit domain)
   max_lsb   largest byte difference on UNORM8 outputs
   n_diff    how many channel values differ at all, of n_total
-into gpurun_out/parity_r05.json (merged back from the GPU box; the copy under profiles/ is the committed record).
+into gpurun_out/parity_r06.json (merged back from the GPU box; the copy under profiles/ is the committed record).
+Content: the synthetic generators of tests/synth.py (structured, uniform-random) and -- round 6 -- NATURAL content: the three fixtures of
+tests/golden/natural_*.npz (rendered game art, a rendered UI with text, a photograph), mirror-tiled to the full sizes (tests/natural.py).
 The asserts are the stated tolerances:
   strict build   bit-exact everywhere (n_diff == 0)
   product build  float outputs max-abs <= 1e-3 (north_star), measured ~3e-6;
@@ -19,7 +21,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests import synth
+from tests import natural, synth
 from tests.util import run_gpu
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +38,7 @@ def _write_report():
         return
     out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "parity_r05.json"), "w") as f:
+    with open(os.path.join(out_dir, "parity_r06.json"), "w") as f:
         json.dump({"note": "HIP path vs CPU oracle at full BASELINE sizes; written by tests/test_gpu_parity_report.py",
                    "records": _RECORDS}, f, indent=1)
 
@@ -59,15 +61,18 @@ def _rec(config, build, content, output, got, want):
     # Regression alarms, NOT the contract (the callers assert that): 4-10x the largest values this report has ever held for the
     # product build at full size (profiles/parity_r05.json: FSR float 2.3e-6, NIS float 8.9e-7, differing UNORM8 bytes 2.2e-5 of
     # an image) -- a change that spends more of the tolerance than that should be looked at before it is believed.
+    # Natural content (round 6) spends more of it in ONE place: the un-quantised float pipeline behind RCAS reads 2.8e-5 on the UI fixture
+    # (EASU alone 6.6e-7 as everywhere: RCAS's 1 / (4 mn - 4) cancels next to white panels, where a contracted 4*mn-4 and the reference's two
+    # roundings differ most) -- still 36 times inside the 1e-3 contract; its alarm is set 3.5x above that measurement.
     if build == "product" and not config.startswith("C5"):   # (C5's float distance is its half rounding: 9.8e-4, asserted by the caller)
         if "max_abs" in r:
-            assert r["max_abs"] <= 1e-5, r
+            assert r["max_abs"] <= (1e-4 if content.startswith("natural") else 1e-5), r
         else:
             assert r["n_diff"] <= 2e-4 * r["n_total"], r
     return r
 
 
-GEN = {"structured": synth.structured_u8, "random": synth.random_u8}
+GEN = {"structured": synth.structured_u8, "random": synth.random_u8, "natural": natural.tiled_u8}
 
 
 def _nis_want(img8, ow, oh, sharp, radius):
@@ -80,7 +85,7 @@ def _nis_want(img8, ow, oh, sharp, radius):
     return O.nis_upscale(O.unorm8_to_float(img8), ow, oh, O.nis_block(cfg, centre, rad, 0), cs, cu)
 
 
-@pytest.mark.parametrize("content", ["structured", "random"])
+@pytest.mark.parametrize("content", ["structured", "random", "natural"])
 def test_c1_easu_only(gpu, content):
     """C1: single left eye 1683x1869 -> 2244x2492 RGBA8, EASU only."""
     iw, ih, ow, oh = 1683, 1869, 2244, 2492
@@ -97,7 +102,7 @@ def test_c1_easu_only(gpu, content):
 
 @pytest.mark.parametrize("cfg,iw,ih,ow,oh,radius", [("C2", 1683, 1869, 2244, 2492, 2.0), ("C2r", 1683, 1869, 2244, 2492, 0.5),
                                                      ("C4", 2244, 2492, 2916, 3240, 2.0)])
-@pytest.mark.parametrize("content", ["structured", "random"])
+@pytest.mark.parametrize("content", ["structured", "random", "natural"])
 def test_fsr_pipeline(gpu, cfg, iw, ih, ow, oh, radius, content):
     """C2 / C2r (shipped radius 0.5) / C4 (renderScale 1.3 shape): EASU -> UNORM8 -> RCAS -> UNORM8, and the same
     pipeline with float intermediate and output (the form north_star's 1e-3 is meaningful on)."""
@@ -124,7 +129,7 @@ def test_fsr_pipeline(gpu, cfg, iw, ih, ow, oh, radius, content):
 
 
 @pytest.mark.parametrize("cfg,radius", [("C3", 2.0), ("C3r", 0.5)])
-@pytest.mark.parametrize("content", ["structured", "random"])
+@pytest.mark.parametrize("content", ["structured", "random", "natural"])
 def test_nis_scaler(gpu, cfg, radius, content):
     """C3 / C3r: NVScaler 1683x1869 -> 2244x2492."""
     iw, ih, ow, oh = 1683, 1869, 2244, 2492
@@ -140,9 +145,10 @@ def test_nis_scaler(gpu, cfg, radius, content):
     assert r["max_lsb"] <= 1, r
 
 
-def _c5_case(gen, seed):
+def _c5_case(gen, seed, scale=1.0):
     iw, ih, ow, oh = 2370, 2370, 3160, 3160
-    imgh = (gen(iw, ih, seed).astype(np.float32) / 255.0).astype(np.float16)
+    imgh = (gen(iw, ih, seed).astype(np.float32) * (scale / 255.0)).astype(np.float16)
+    imgh[..., 3] = np.float16(1.0)
     centre, rad = O.mask_constants(ow, oh, 0.5)
     e = O.easu(imgh.astype(np.float32), ow, oh, O.easu_con(iw, ih, ow, oh), centre, rad)
     e16 = e.astype(np.float16).astype(np.float32)
@@ -164,6 +170,28 @@ def test_c5_masked_half(gpu, content, seed):
     assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
 
 
+@pytest.mark.parametrize("seed,scale", [(0, 1.0), (1, 1.0), (2, 1.0), (0, 6.0), (2, 6.0)])
+def test_c5_masked_half_natural(gpu, seed, scale):
+    """C5 on natural content (round 6): the three fixtures as RGBA16F at unit range, and two of them as HDR -- half(b / 255 * 6): highlights
+    six times the unit range next to dark texels, what the half guard's footprint-scaled band exists for.  Strict bit-exact; product within
+    1e-3 on every value of the unit-range images, within max(1e-3, one half spacing of the value) on the HDR ones (header contract)."""
+    ow, oh = 3160, 3160
+    imgh, want = _c5_case(natural.tiled_u8, seed, scale)
+    tag = "natural (%s%s)" % (natural.NAMES[seed % 3], "" if scale == 1.0 else " x%g HDR" % scale)
+    r = _rec("C5", "strict", tag, "half", run_gpu(imgh, ow, oh, np.float16, precision=STRICT, sharpness=0.9, radius=0.5), want)
+    assert r["n_diff"] == 0
+    got = run_gpu(imgh, ow, oh, np.float16, precision=FP32, sharpness=0.9, radius=0.5)
+    r = _rec("C5", "product", tag, "half", got, want)
+    if scale == 1.0:
+        assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
+    else:
+        w32, g32 = want.astype(np.float32), got.astype(np.float32)
+        spacing = np.maximum(np.exp2(np.floor(np.log2(np.maximum(np.abs(w32), 2.0 ** -14)))) * 2.0 ** -10, 0.0)
+        over = np.abs(g32 - w32) > np.maximum(1e-3, spacing) * 1.0001
+        r["n_beyond_contract"] = int(over.sum())
+        assert r["n_beyond_contract"] == 0, r
+
+
 @pytest.mark.parametrize("cfg", ["C2", "C2r", "C5", "C2sbsr"])
 def test_timed_call_full_size(gpu, cfg):
     """The call bench.py times -- ovrfsr_apply_batch over a batch of full-size images (L,R,L,R..., blockIdx.z > 0, XCD-ordered
@@ -178,7 +206,7 @@ def test_timed_call_full_size(gpu, cfg):
     if shared:
         n = 3
     half = cfg == "C5"
-    gens = [synth.structured_u8, synth.structured_u8, synth.random_u8]
+    gens = [synth.structured_u8, natural.tiled_u8, synth.random_u8]
     imgs8 = [gens[i % 3](iw, ih, synth.seed_for(10 + i // 2, i & 1)) for i in range(n)]
     if half:
         src = np.stack([(im.astype(np.float32) / 255.0).astype(np.float16) for im in imgs8])
@@ -200,7 +228,7 @@ def test_timed_call_full_size(gpu, cfg):
             want = O.rcas(e.astype(np.float16).astype(np.float32), O.rcas_con(0.9), centre, rad).astype(np.float16)
         else:
             want = O.fsr_pipeline_u8(imgs8[i], ow, oh, sharpness=0.9, radius=radius, eye=eye, one_eye_per_texture=not shared)
-        r = _rec(cfg + " batched (image %d of %d)" % (i, n), "product", "random" if i % 3 == 2 else "structured",
+        r = _rec(cfg + " batched (image %d of %d)" % (i, n), "product", ("structured", "natural", "random")[i % 3],
                  "half" if half else "unorm8", got[i], want)
         if half:
             assert r["max_abs"] <= 1e-3 and r["n_gt_1e-3"] == 0, r
@@ -208,7 +236,7 @@ def test_timed_call_full_size(gpu, cfg):
             assert r["max_lsb"] <= 1, r
 
 
-@pytest.mark.parametrize("content", ["structured", "random"])
+@pytest.mark.parametrize("content", ["structured", "random", "natural"])
 def test_sharpen_only_configs(gpu, content):
     """renderScale 1 at 2244x2492 (PostProcessor.cpp:586-594: no upscale stage): RCAS alone (C2s, the DPP kernel) and NVSharpen
     alone (C3s)."""

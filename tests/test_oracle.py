@@ -195,3 +195,45 @@ def test_oracle_matches_reference_on_adversarial_patches(ow, seed, mutated):
     q = O.unorm8_to_float(O.float_to_unorm8(a))
     rcon = O.rcas_con(0.9, 0)
     assert same_bits(O.rcas(q, rcon, centre, rad), O.ref_rcas(q, rcon, centre, rad))
+
+
+# ---- natural content (round 6): the three fixtures of tests/golden/natural_*.npz -------------------------------------------------------
+@pytest.mark.parametrize("name", ["cube", "portal", "hopper"])
+def test_oracle_matches_natural_golden(name):
+    """the oracle's EASU / EASU->RCAS / NVScaler outputs on the natural-content fixtures at 256 -> 341, as SHA-256 digests cut where
+    /root/reference was present (tests/golden/make_natural.py): a change of the oracle (or of the fixtures) is a failure here, GPU or not"""
+    import json
+    import os
+    from tests import natural
+    gold = json.load(open(os.path.join(natural.GOLD, "natural_golden.json")))
+    img = natural.load(name)
+    assert img.shape == (256, 256, 4) and img.dtype == np.uint8 and (img[..., 3] == 255).all() and img[..., :3].std() > 40
+    assert natural.oracle_digests(img) == gold[name]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
+@pytest.mark.parametrize("name", ["cube", "portal", "hopper"])
+@pytest.mark.parametrize("ow,radius", [(341, 2.0), (341, 0.5), (333, 0.7), (512, 2.0)])
+def test_oracle_matches_reference_on_natural_content(name, ow, radius):
+    """... and the restatement against the reference's own HLSL text compiled here, bit for bit, on the same natural images: EASU (real
+    edges: the dering clamp and the 1/32768 zero-direction branch, ffx_fsr1.h:388-437), RCAS behind the UNORM8 intermediate, NVScaler's edge
+    classification (NIS_Scaler.h:176-293)"""
+    from tests import natural
+    img8 = natural.load(name)
+    img = O.unorm8_to_float(img8)
+    con = O.easu_con(256, 256, ow, ow)
+    centre, rad = O.mask_constants(ow, ow, radius, (0.45, 0.55, 0.6, 0.5), True, 0)
+    a = O.easu(img, ow, ow, con, centre, rad)
+    assert same_bits(a, O.ref_easu(img, ow, ow, con, centre, rad))
+    q = O.unorm8_to_float(O.float_to_unorm8(a))
+    rcon = O.rcas_con(0.9, 0)
+    assert same_bits(O.rcas(q, rcon, centre, rad), O.ref_rcas(q, rcon, centre, rad))
+    cs, cu = O.ref_nis_coefs()
+    ok, cfg = O.ref_nis_scaler_config(0.9, 256, 256, ow, ow)
+    assert ok
+    blk = O.nis_block(cfg, centre, rad, 0)
+    assert same_bits(O.nis_upscale(img, ow, ow, blk, cs, cu), O.ref_nis_upscale(img, ow, ow, blk, cs, cu))
+    ok, cfg = O.ref_nis_scaler_config(0.9, 256, 256, 256, 256)
+    c2, r2 = O.mask_constants(256, 256, radius, (0.45, 0.55, 0.6, 0.5), True, 0)
+    blk = O.nis_block(cfg, c2, r2, 0)
+    assert same_bits(O.nis_sharpen(img, blk), O.ref_nis_sharpen(img, blk, cs, cu))

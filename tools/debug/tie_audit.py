@@ -10,7 +10,7 @@ It also records the largest |product - strict| it met (bytes of the UNORM8 domai
 
     OVRFSR_LIB=$PWD/ab/audit.so python tools/debug/tie_audit.py [scale=1.0]      (GPU; `scale` multiplies the images per configuration)
 
-Content: the bench's structured and uniform-random generators, 0 / 255-heavy images, and a mosaic of 8x8-texel patches of the families the
+Content: natural images (round 6: tests/golden/natural_*.npz, mirror-tiled), the bench's structured and uniform-random generators, 0 / 255-heavy images, and a mosaic of 8x8-texel patches of the families the
 adversarial search (tools/debug/easu_err_search.py) mutates -- two-level edges at random angles, ramps with noise, near-constant patches with
 outliers, extremes --; for the half pipelines the same content as half(b / 255 * s), s in {1, 6, 40} (unit range and HDR).
 Shapes: BASELINE C2 (x4/3), C4 (x1.3), C5 (x4/3, masked and unmasked, half), and odd ratios (x1.7, x1.11, x2)."""
@@ -79,6 +79,8 @@ def mosaic_batch(n, w, h, seed, P=8):
 
 
 CONTENT = {
+    # round 6: NATURAL content -- the fixtures of tests/golden/natural_*.npz (rendered game art, a rendered UI with text, a photograph), mirror-tiled
+    "natural": lambda n, w, h, s: bench.natural_batch(n, w, h, torch.uint8, DEV, s),
     "structured": lambda n, w, h, s: bench.synth_batch(n, w, h, torch.uint8, DEV, s),
     "random": lambda n, w, h, s: bench.random_batch(n, w, h, torch.uint8, DEV, s),
     "extremes": extremes_batch,
@@ -118,18 +120,18 @@ def main():
     t0 = time.time()
     seed = 0x5EED0000
     C2 = (1683, 1869, 2244, 2492)
-    for content in ("structured", "random", "extremes", "mosaic"):
+    for content in ("structured", "random", "extremes", "mosaic", "natural"):
         for rep in range(2):
             seed += 1000
             acc(run("C2 two-pass RGBA8 (easu_fast_kernel -> UNORM8 intermediate)", *C2, content, N(24), seed, radius=2.0))
-    for content in ("structured", "mosaic", "random"):
+    for content in ("structured", "mosaic", "random", "natural"):
         seed += 1000
         acc(run("C2 fused=1 (fused_kernel, UNORM8 plane)", *C2, content, N(8), seed, radius=2.0, fused=1))
         seed += 1000
         acc(run("C2r masked sorted (radius 0.5)", *C2, content, N(16), seed, radius=0.5))
         seed += 1000
         acc(run("C2 EASU only -> UNORM8 output", *C2, content, N(8), seed, radius=2.0, stage_mask=1))
-    for content in ("structured", "mosaic", "random"):
+    for content in ("structured", "mosaic", "random", "natural"):
         seed += 1000
         acc(run("C4 x1.3 two-pass RGBA8", 2244, 2492, 2916, 3240, content, N(8), seed, radius=2.0))
     for (iw, ih, ow, oh, name) in ((1000, 900, 1695, 1525, "x1.7"), (1000, 900, 1111, 1000, "x1.11"), (1000, 900, 2000, 1800, "x2"), (997, 811, 1329, 1081, "x4/3 odd")):
@@ -138,7 +140,7 @@ def main():
             acc(run("odd ratio %s two-pass RGBA8" % name, iw, ih, ow, oh, content, N(16), seed, radius=2.0))
     C5 = (2370, 2370, 3160, 3160)
     for hs in (1.0, 6.0, 40.0):
-        for content in ("structured", "mosaic", "random"):
+        for content in ("structured", "mosaic", "random", "natural"):
             seed += 1000
             acc(run("C5 masked half pipeline (fused_kernel, half plane)", *C5, content, N(6), seed, half_scale=hs, radius=0.5))
             seed += 1000
