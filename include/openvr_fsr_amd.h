@@ -82,6 +82,14 @@ typedef enum ovrfsr_format {
  *                outputs by <= 1 LSB, half pipeline outputs by <= 1e-3 on unit-range images and by <= one half-ulp of the value beyond
  *   FP32_STRICT  fp32, every operator evaluated as written (no FMA), IEEE division: bit-identical
  *                to the CPU oracle; a validation build, not a fast one
+ * Pixels OUTSIDE the radius (the reference's `Bilinear` fallback, fsr_easu.hlsl:33-36, and NIS `DirectCopy`, NIS_Upscale.hlsl:77-90 --
+ * 78 % of a frame at the shipped radius 0.5) and NVScaler's chroma tap are one SampleLevel through D3D11's default linear-clamp sampler.
+ * Both builds evaluate it as the D3D11 functional spec describes that sampler -- texel coordinate snapped to 8 fractional bits, round to
+ * nearest, weights applied unfused -- and are bit-identical to the oracle there.  That reading is a restatement of the spec, not of anything
+ * in the reference (it is fixed-function hardware), so its exposure is stated instead of its proof (profiles/r06_sampler_exposure.txt): if
+ * hardware keeps MORE sub-texel bits (10, 12, exact float weights), pixels outside the radius move by <= 1 LSB -- none at all at BASELINE's
+ * C2 / C3 shape, whose scale is exactly 3/4 (every coordinate a multiple of 1/4), 1.9 % of the bytes at x1.3 (C4 shape) on structured and
+ * natural content, 10.8 % on uniform noise; a TRUNCATING snap would move 0.6 % / 3.9 % of them by <= 2 LSB.
  * There is no packed-half arithmetic mode (value 1 was reserved for one in ABI 1 and is rejected with
  * OVRFSR_ERR_INVALID_ARGUMENT by ovrfsr_create / ovrfsr_set_config): on gfx950 v_pk_*_f16 issues at the rate of
  * v_pk_*_f32 (profiles/r02_valu_issue_rates.txt), the fp32 kernels already process two taps per packed instruction, and

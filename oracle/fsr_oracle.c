@@ -298,6 +298,23 @@ static inline void fixed8(float t, int *i0, float *frac)
     *frac = (s - f * 256.0f) * (1.0f / 256.0f);
 }
 
+/* The sampler model.  Default = the D3D11 functional spec as oracle/hlsl_shim.hpp restates it: 8 fractional bits, round to nearest.
+ * Nothing in the reference can pin this (it is fixed-function hardware behaviour), so the EXPOSURE to it is measured instead
+ * (tools/debug/sampler_exposure.py): ovo_set_sampler_model(bits, truncate) switches this library -- and nothing
+ * else: not the product, not oracle/_ref -- to `bits` fractional bits (0 = exact float weights, no snap) with a rounding or truncating
+ * snap.  Test infrastructure; every test and fixture runs with the default. */
+int g_ovo_sampler_bits = 8, g_ovo_sampler_trunc = 0;
+OVO_API void ovo_set_sampler_model(int bits, int truncate) { g_ovo_sampler_bits = bits; g_ovo_sampler_trunc = truncate; }
+static inline void fixed_model(float t, int *i0, float *frac)
+{
+    if (g_ovo_sampler_bits <= 0) { float f = floorf(t); *i0 = (int)f; *frac = t - f; return; }
+    const float one = (float)(1 << g_ovo_sampler_bits);
+    float s = g_ovo_sampler_trunc ? floorf(t * one) : floorf(t * one + 0.5f);
+    float f = floorf(s / one);
+    *i0 = (int)f;
+    *frac = (s - f * one) / one;
+}
+
 /* bilinear SampleLevel with linear/clamp sampler at normalised (u,v); fsr_easu.hlsl:33-36 */
 static void sample_bilinear(float out[4], const image_t *im, float u, float v)
 {
@@ -305,8 +322,8 @@ static void sample_bilinear(float out[4], const image_t *im, float u, float v)
     float ty = v * (float)im->h - 0.5f;
     int x0, y0;
     float fx, fy;
-    fixed8(tx, &x0, &fx);
-    fixed8(ty, &y0, &fy);
+    if (g_ovo_sampler_bits == 8 && !g_ovo_sampler_trunc) { fixed8(tx, &x0, &fx); fixed8(ty, &y0, &fy); }
+    else { fixed_model(tx, &x0, &fx); fixed_model(ty, &y0, &fy); }
     const float *c00 = texel_clamp(im, x0, y0), *c10 = texel_clamp(im, x0 + 1, y0);
     const float *c01 = texel_clamp(im, x0, y0 + 1), *c11 = texel_clamp(im, x0 + 1, y0 + 1);
     float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy);

@@ -69,13 +69,23 @@ static inline void fixed8(float t, int *i0, float *frac)
     *i0 = (int)f;
     *frac = (s - f * 256.0f) * (1.0f / 256.0f);
 }
+extern int g_ovo_sampler_bits, g_ovo_sampler_trunc; /* fsr_oracle.c: the sampler model of the exposure study (default 8 bits, rounding) */
+static inline void fixed_model(float t, int *i0, float *frac)
+{
+    if (g_ovo_sampler_bits <= 0) { float f = floorf(t); *i0 = (int)f; *frac = t - f; return; }
+    const float one = (float)(1 << g_ovo_sampler_bits);
+    float s = g_ovo_sampler_trunc ? floorf(t * one) : floorf(t * one + 0.5f);
+    float f = floorf(s / one);
+    *i0 = (int)f;
+    *frac = (s - f * one) / one;
+}
 static void sample_bilinear(float out[4], const image_t *im, float u, float v)
 {
     float tx = u * (float)im->w - 0.5f, ty = v * (float)im->h - 0.5f;
     int x0, y0;
     float fx, fy;
-    fixed8(tx, &x0, &fx);
-    fixed8(ty, &y0, &fy);
+    if (g_ovo_sampler_bits == 8 && !g_ovo_sampler_trunc) { fixed8(tx, &x0, &fx); fixed8(ty, &y0, &fy); }
+    else { fixed_model(tx, &x0, &fx); fixed_model(ty, &y0, &fy); }
     const float *c00 = texel_clamp(im, x0, y0), *c10 = texel_clamp(im, x0 + 1, y0);
     const float *c01 = texel_clamp(im, x0, y0 + 1), *c11 = texel_clamp(im, x0 + 1, y0 + 1);
     float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
