@@ -44,6 +44,8 @@ PATCHED = [
     ("rpipe", "-DOVRFSR_RCAS_PIPE", "rcas_pipe"),
     ("px2", "-DOVRFSR_RCAS_PX2", "rcas_px2"),
     ("rlds", "", "rcas_lds_cap"),
+    # round 6: the fused kernel as a persistent workgroup prefetching the next tile's texels (profiles/r06_fused_prefetch.txt)
+    ("pf", "-DOVRFSR_FUSED_PF_DEFAULT=1 -DOVRFSR_FUSED_PF_WAVES=6", "fused_prefetch"),
 ]
 
 pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

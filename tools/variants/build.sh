@@ -13,6 +13,7 @@
 #   PATCHES=easu_fs_bundle tools/variants/build.sh fsb "-DOVRFSR_EASU_FS_BUNDLE [-DOVRFSR_EASU_OCC5]" | mme "-DOVRFSR_EASU_MM_EARLY"   profiles/r05_sched_ab.txt
 #   PATCHES=rcas_px2 tools/variants/build.sh px2 "-DOVRFSR_RCAS_PX2 [-DOVRFSR_RCAS_PX2_WAVES=N]"  (run with OVRFSR_RCAS_PX2=32|16)   profiles/r05_sched_ab.txt (7)
 #   tools/variants/build.sh nishalf  "-DOVRFSR_NIS_HALF_LDS"       profiles/r03_nis_variants.txt
+#   PATCHES=fused_prefetch tools/variants/build.sh pf6 "-DOVRFSR_FUSED_PF_WAVES=6"  (run with OVRFSR_FUSED_PF=1 [OVRFSR_FUSED_TPW=N])       profiles/r06_fused_prefetch.txt
 set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 NAME=$1; EXTRA=$2; MODE=${3:-}

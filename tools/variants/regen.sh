@@ -7,7 +7,7 @@ set -e
 ROOT="$(cd "$(dirname "$0")/../.." && pwd)"; cd "$ROOT"
 BASE=$(cat tools/variants/BASE)
 S=$(mktemp -d /tmp/ovrfsr_regen_XXXXXX)
-for P in ${PATCH_LIST:-fsr_variants nis_variants easu_fs_bundle easu_soa rcas_pipe rcas_px2 rcas_lds_cap}; do
+for P in ${PATCH_LIST:-fsr_variants nis_variants easu_fs_bundle easu_soa rcas_pipe rcas_px2 rcas_lds_cap fused_prefetch}; do
   FILES=$(grep '^+++ ' tools/variants/$P.patch | sed 's#^+++ [ab]/##; s#\t.*##')
   mkdir -p $S/$P/base/openvr_fsr_amd/csrc $S/$P/theirs/openvr_fsr_amd/csrc $S/$P/a/openvr_fsr_amd/csrc $S/$P/b/openvr_fsr_amd/csrc
   for F in $FILES; do git show $BASE:$F > $S/$P/base/$F; cp $S/$P/base/$F $S/$P/theirs/$F; done
