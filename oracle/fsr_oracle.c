@@ -300,7 +300,7 @@ static inline void fixed8(float t, int *i0, float *frac)
 
 /* The sampler model.  Default = the D3D11 functional spec as oracle/hlsl_shim.hpp restates it: 8 fractional bits, round to nearest.
  * Nothing in the reference can pin this (it is fixed-function hardware behaviour), so the EXPOSURE to it is measured instead
- * (tools/debug/sampler_exposure.py): ovo_set_sampler_model(bits, truncate) switches this library -- and nothing
+ * (tests/debug/sampler_exposure.py): ovo_set_sampler_model(bits, truncate) switches this library -- and nothing
  * else: not the product, not oracle/_ref -- to `bits` fractional bits (0 = exact float weights, no snap) with a rounding or truncating
  * snap.  Test infrastructure; every test and fixture runs with the default. */
 int g_ovo_sampler_bits = 8, g_ovo_sampler_trunc = 0;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/debug/sampler_exposure.py -- how much of the output depends on the ONE thing nothing in the reference can pin: the D3D11 sampler.
+"""tests/debug/sampler_exposure.py -- how much of the output depends on the ONE thing nothing in the reference can pin: the D3D11 sampler.
 
 78 % of the pixels at the reference's shipped radius 0.5 go through `Bilinear` (fsr_easu.hlsl:33-36) / `DirectCopy` (NIS_Upscale.hlsl:77-90):
 one SampleLevel through the default linear-clamp sampler.  oracle/hlsl_shim.hpp restates that sampler from the D3D11 functional spec -- texel
@@ -8,7 +8,7 @@ can see an error in it, and no D3D runtime exists here to check it against.  Wha
 oracle with other sampler models (6 / 10 / 12 fractional bits, a truncating snap, exact float weights) and reports how far the final UNORM8
 output moves -- per configuration, over the pixels outside the radius and (NVScaler's chroma tap goes through the same sampler) inside it.
 
-    python tools/debug/sampler_exposure.py [--quick]        (CPU only; ~2 min at full size on 8 cores)   -> profiles/r06_sampler_exposure.txt"""
+    python tests/debug/sampler_exposure.py [--quick]        (CPU only; ~2 min at full size on 8 cores)   -> profiles/r06_sampler_exposure.txt"""
 import ctypes
 import os
 import sys

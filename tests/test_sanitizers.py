@@ -46,14 +46,14 @@ def test_host_tests_clean_under_asan_ubsan():
     assert " passed" in r.stdout, r.stdout[-500:]
 
 
-def test_sanitizer_build_is_live():
+def test_sanitizer_build_is_live(tmp_path):
     """the instrumented library does report: the un-fixed conversion of round 5 (a negative float cast to uint32) is re-created in a probe
     translation unit compiled with the same flags; UBSan must name it -- otherwise a clean run above says nothing"""
     rt = _build()
     clang = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin", "clang")
-    src = os.path.join(ROOT, "ab", "ubsan_probe.c")
+    src = str(tmp_path / "ubsan_probe.c")
     open(src, "w").write("#include <stdint.h>\n#include <stdio.h>\nint main(int c, char **v) { volatile float r = -1.0f * c; uint32_t u = (uint32_t)(0.5f * r * 2492); printf(\"%u\\n\", u); return 0; }\n")
-    exe = os.path.join(ROOT, "ab", "ubsan_probe")
+    exe = str(tmp_path / "ubsan_probe")
     subprocess.check_call([clang, "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", src, "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode != 0 and "runtime error" in r.stderr and "outside the range of representable values" in r.stderr, r.stderr

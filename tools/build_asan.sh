@@ -18,21 +18,23 @@ make -C "$ROOT/openvr_fsr_amd/csrc" -j8 EXTRA="$SAN --offload-compress" LDEXTRA=
 test -f "$ROOT/ab/asan.so"
 ROCM=${ROCM_PATH:-/opt/rocm}
 for ex in headless bench_node; do
-    $CLANG -std=c11 -O1 -g $SAN -pthread -D_POSIX_C_SOURCE=200809L -D__HIP_PLATFORM_AMD__ "$ROOT/examples/$ex.c" -I"$ROOT/include" -I"$ROCM/include" \
-        "$ROOT/ab/asan.so" -L"$ROCM/lib" -lamdhip64 -lm -Wl,-rpath,"\$ORIGIN" -Wl,-rpath,"$ROCM/lib" -o "$ROOT/ab/${ex}_asan"
+    # (-shared-libasan: the drivers use the runtime as a shared object -- 30 KB each instead of 3.2 MB of statically linked runtime to push to the GPU box)
+    $CLANG -std=c11 -O1 -g $SAN -shared-libasan -pthread -D_POSIX_C_SOURCE=200809L -D__HIP_PLATFORM_AMD__ "$ROOT/examples/$ex.c" -I"$ROOT/include" -I"$ROCM/include" \
+        "$ROOT/ab/asan.so" -L"$ROCM/lib" -lamdhip64 -lm -Wl,-rpath,"\$ORIGIN" -Wl,-rpath,"$ROCM/lib" -Wl,-rpath,"$(dirname "$RT")" -o "$ROOT/ab/${ex}_asan"
 done
 # The same host translation units under GCC's AddressSanitizer + UBSan, linked with the PRODUCT's kernel objects -> ab/asan_gcc.so: the one
 # a Python process that also holds torch can load on the GPU box (LD_PRELOAD of gcc's libasan / libubsan).  ROCm's clang ASan runtime
 # intercepts hsa_amd_memory_pool_allocate for GPU-ASan and cannot be preloaded into a process whose HIP runtime is torch's private,
 # uninstrumented copy ("AddressSanitizer: out of memory" at the first device allocation) -- the plain-C drivers above, which link
 # /opt/rocm's runtime directly, are fine with it.
-make -C "$ROOT/openvr_fsr_amd/csrc" -j8 build/fsr_kernels.o build/nis_kernels.o >/dev/null
+# (the product's kernel translation units once more with a zstd-compressed fat binary: 0.8 instead of 3.4 MB to push)
+make -C "$ROOT/openvr_fsr_amd/csrc" -j8 EXTRA=--offload-compress BUILD=build_z build_z/fsr_kernels.o build_z/nis_kernels.o >/dev/null
 mkdir -p "$ROOT/openvr_fsr_amd/csrc/build_asan_gcc"
 for f in postprocessor constants nis_config config_json capi; do
     g++ -std=c++17 -O1 -g -fPIC -fvisibility=hidden -D__HIP_PLATFORM_AMD__ -I"$ROCM/include" -ffp-contract=off $SAN \
         -c "$ROOT/openvr_fsr_amd/csrc/$f.cpp" -o "$ROOT/openvr_fsr_amd/csrc/build_asan_gcc/$f.o"
 done
 ${HIPCC:-$ROCM/bin/hipcc} --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/asan_gcc.so" "$ROOT"/openvr_fsr_amd/csrc/build_asan_gcc/*.o \
-    "$ROOT/openvr_fsr_amd/csrc/build/fsr_kernels.o" "$ROOT/openvr_fsr_amd/csrc/build/nis_kernels.o"
+    "$ROOT/openvr_fsr_amd/csrc/build_z/fsr_kernels.o" "$ROOT/openvr_fsr_amd/csrc/build_z/nis_kernels.o"
 python3 "$ROOT/tools/variant_fresh.py" --stamp asan "$SAN"
 echo "built ab/asan.so ab/asan_gcc.so ab/headless_asan ab/bench_node_asan"
