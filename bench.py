@@ -202,6 +202,11 @@ class GpuShard:
         self.pp.close()
 
 
+# OVRFSR_BENCH_TIMED_GAP_MS (profiling aid, default off): milliseconds of host sleep right before and right after the timed steps, outside the
+# timed region.  The device idles for that long, which brackets the timed dispatches in a rocprofv3 kernel trace (tools/profile.sh sets 3).
+TIMED_GAP_S = float(os.environ.get("OVRFSR_BENCH_TIMED_GAP_MS", "0") or 0) * 1e-3
+
+
 def build_shards(n_local, first_shard, make):
     """The launcher's partition: shard i of this process = global shard first_shard + i on local device i."""
     return [make(i, first_shard + i) for i in range(n_local)]
@@ -236,12 +241,16 @@ def run_local(shards, steps, warmup, ramp_s=0.0, cross_barrier=None):
             if i == 0:
                 all_ranks()
             gate.wait()
+            if TIMED_GAP_S:
+                time.sleep(TIMED_GAP_S)   # profiling aid (tools/profile.sh): an idle gap in the kernel trace in front of the timed steps
             t_start[i] = time.perf_counter()
             s.mark_start()
             for _ in range(steps):
                 s.step()
             s.mark_end()
             s.sync()
+            if TIMED_GAP_S:
+                time.sleep(TIMED_GAP_S)   # ... and behind them (outside the timed region on both sides)
             gate.wait()
             if i == 0:
                 all_ranks()

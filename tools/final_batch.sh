@@ -1,7 +1,23 @@
 #!/bin/bash
-# final measurements of the round (run from the repo root on the GPU box)
-python bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; tail -c 600 gpurun_out/r05_bench_default.json
-tools/bench_all.sh gpurun_out/r05_bench_all_workloads.txt > /dev/null 2>&1; cat gpurun_out/r05_bench_all_workloads.txt | cut -c1-200
-for W in C2 C2r C3 C4 C5 C2sbsr; do tools/profile.sh r05_final_$(echo $W | tr A-Z a-z) --workload $W --steps 10 --warmup 3 > /dev/null 2>&1; done
+# final measurements of the round (run from the repo root on the GPU box): everything on ONE box, so that the default bench line, the workload
+# table and the rocprofv3 summaries under profiles/ can be read against each other
+R=r06
+python bench.py > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.err; tail -c 600 gpurun_out/${R}_bench_default.json
+tools/bench_all.sh gpurun_out/${R}_bench_all_workloads.txt > /dev/null 2>&1; cat gpurun_out/${R}_bench_all_workloads.txt | cut -c1-200
+for W in C2 C2r C3 C4 C5 C2sbsr; do tools/profile.sh ${R}_final_$(echo $W | tr A-Z a-z) --workload $W --steps 20 --warmup 5 > /dev/null 2>&1; done
 ls gpurun_out/profile/
-python -m pytest tests/test_gpu_parity_report.py -q 2>&1 | tail -2
+# the same default line once more at the end (box drift over the batch) and the consistency the judge asked for: kernel durations of the
+# traced C2 run against that run's own step and against the un-profiled line of this box
+python bench.py --no-cpu --no-extras --pmc off > gpurun_out/${R}_bench_default_end.json 2>/dev/null
+python - <<'PY'
+import csv, json, re
+d = json.loads(open("gpurun_out/r06_bench_default.json").read().strip().splitlines()[-1])
+e = json.loads(open("gpurun_out/r06_bench_default_end.json").read().strip().splitlines()[-1])
+ks = {r["Name"]: float(r["NsPerStep"]) / 1e6 for r in csv.DictReader(l for l in open("gpurun_out/profile/r06_final_c2/timed_kernel_stats.csv") if not l.startswith("#")) if "ovrfsr" in r["Name"]}
+easu = sum(v for k, v in ks.items() if "easu_fast_kernel" in k); rcas = sum(v for k, v in ks.items() if "rcas_dpp_kernel" in k)
+traced = json.loads([l for l in open("gpurun_out/profile/r06_final_c2/bench_under_kernel_trace.log") if l.startswith("{")][-1])
+txt = ("same box: default line ms_per_step %.4f (events inside the timed loop %.4f), end-of-batch line %.4f; rocprofv3 --kernel-trace --stats of the same command: "
+       "EASU %.4f + RCAS %.4f = %.4f ms per step of 64 pairs over the dispatches of the timed steps (timed_kernel_stats.csv), the traced run's own ms_per_step %.4f\n"
+       % (d["ms_per_step"], d["roofline"]["pipeline_ms_per_step_events"], e["ms_per_step"], easu, rcas, easu + rcas, traced["ms_per_step"]))
+open("gpurun_out/r06_consistency.txt", "w").write(txt); print(txt)
+PY
