@@ -147,6 +147,14 @@ template <typename U, typename T> __device__ __forceinline__ U *at(const ptr<T> 
     static_assert(std::is_const<U>::value || !std::is_const<T>::value, "access drops const");
     return const_cast<U *>(reinterpret_cast<const U *>(s.check(reinterpret_cast<const char *>(s.p), sizeof(U))));
 }
+// the same for an access whose size is not sizeof(U): a 3-element ext_vector is 16 bytes to sizeof and 12 bytes to the load that fetches it
+// (global_load_dwordx3) -- checked as 16 it "reaches" 4 bytes past a row it ends flush with, and the redirect that follows corrupts pixels of the
+// CHECKED build only (found by running the fuzz seeds against it: 12 of 9 750 instances)
+template <typename U, unsigned BYTES, typename T> __device__ __forceinline__ U *at_n(const ptr<T> &s)
+{
+    static_assert(std::is_const<U>::value || !std::is_const<T>::value, "access drops const");
+    return const_cast<U *>(reinterpret_cast<const U *>(s.check(reinterpret_cast<const char *>(s.p), BYTES)));
+}
 // raw pointers pass through (host-side tables handed to helpers that are also used unchecked) -- not used by the kernels
 template <typename U, typename T> __device__ __forceinline__ U *at(T *s) { return reinterpret_cast<U *>(s); }
 
@@ -182,6 +190,7 @@ template <typename T> __device__ __forceinline__ T *raw(const ptr<T> &s) { retur
 #define OVRFSR_IMAGE(T, base, pitch, w, h, texel, kind) ovrfsr_chk::image<T>((base), (pitch), (w), (h), (texel), ovrfsr_chk::kind)
 #define OVRFSR_AS(T, e) ovrfsr_chk::cast<T>(e)                             /* reinterpret the element type; index / dereference through the result */
 #define OVRFSR_AT(T, e) ovrfsr_chk::at<T>(e)                               /* raw T* of one validated access (under-aligned vector typedefs) */
+#define OVRFSR_AT_N(T, bytes, e) ovrfsr_chk::at_n<T, bytes>(e)             /* ... of `bytes` bytes (3-element vectors: 12, not sizeof = 16) */
 #define OVRFSR_RAW(e) ovrfsr_chk::raw(e)                                   /* the unchecked pointer (to carve the next plane from) */
 #define OVRFSR_LDS_ARRAY(T, name, n, kind) __shared__ T name##_lds[n]; const ovrfsr_chk::ptr<T> name(name##_lds, (n), 0, ovrfsr_chk::kind)
 #else
@@ -195,6 +204,7 @@ template <typename T> __device__ __forceinline__ T *raw(const ptr<T> &s) { retur
 #define OVRFSR_IMAGE(T, base, pitch, w, h, texel, kind) (base)
 #define OVRFSR_AS(T, e) reinterpret_cast<T *>(e)
 #define OVRFSR_AT(T, e) reinterpret_cast<T *>(e)
+#define OVRFSR_AT_N(T, bytes, e) reinterpret_cast<T *>(e)
 #define OVRFSR_RAW(e) (e)
 #define OVRFSR_LDS_ARRAY(T, name, n, kind) __shared__ T name[n]
 #endif

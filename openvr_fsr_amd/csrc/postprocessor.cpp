@@ -202,18 +202,23 @@ void PostProcessor::PrepareUpscalingResources()
     float sx, sy, cx, cy;
     std::memcpy(&sx, &easuCon_[0], 4); std::memcpy(&sy, &easuCon_[1], 4);
     std::memcpy(&cx, &easuCon_[2], 4); std::memcpy(&cy, &easuCon_[3], 4);
-    // LDS footprint of one 32x32 output tile: f-texel of first and last pixel, +1/+2 apron
-    auto extent = [](uint32_t outN, int tile, float s, float c) {
+    // LDS footprint of one 32x32 output tile: f-texel of first and last pixel, +1/+2 apron.  `pairs`: the product EASU kernel resolves rows in
+    // PAIRS (ly, ly + 1), ly even, and evaluates the second pixel of the last pair even when its row lies behind the image (only its store is
+    // guarded): the footprint covers that row too.  (Until round 6 it did not: where the LAST, partial tile row defines the extent -- an image of
+    // a single tile row with an odd height -- the discarded pixel read up to two cell rows past the colour / analysis planes, into the next
+    // plane of the same workgroup.  Found by the fuzz seeds run against the checked build, seed 162312: profiles/r06_bounds.txt.)
+    auto extent = [](uint32_t outN, int tile, float s, float c, bool pairs) {
         int best = 0;
         for (uint32_t o0 = 0; o0 < outN; o0 += tile) {
             uint32_t o1 = o0 + tile - 1 < outN ? o0 + tile - 1 : outN - 1;
+            if (pairs) o1 |= 1u; // the partner row of the last pair (inside the tile: tile heights are even)
             int f0 = (int)std::floor(mad2((float)o0, s, c)), f1 = (int)std::floor(mad2((float)o1, s, c));
             best = f1 - f0 + 4 > best ? f1 - f0 + 4 : best;
         }
         return best;
     };
-    cellsW_ = extent(outputWidth_, kTileW, sx, cx);
-    cellsH_ = extent(outputHeight_, kTileH, sy, cy);
+    cellsW_ = extent(outputWidth_, kTileW, sx, cx, false);
+    cellsH_ = extent(outputHeight_, kTileH, sy, cy, true);
     // fused kernel: EASU runs on the tile plus a 1-pixel ring, origin at pixel (o0 - 1)
     auto extentRing = [](uint32_t outN, int tile, float s, float c) {
         int best = 0;

@@ -28,7 +28,7 @@ def test_checked_build_finds_no_out_of_bounds_access(gpu):
     # the self-test launch commits every kind of violation once and must be COUNTED exactly: a zero below is then a finding, not silence
     assert selftest == "ok", r.stdout[:600]
     assert r.returncode == 0 and oob == 0 and badpad == 0, r.stdout[-3000:]
-    assert configs > 1500 and checked > 5e9, (configs, checked)
+    assert configs > 2500 and checked > 5e9, (configs, checked)
     # the canary: the analysis sweep of EASU does read its declared luma pad rows (fsr_params.h kLumPadRows) -- the accessors are live in the
     # kernels, not only in the self-test -- and nothing else than the declared kinds shows pad accesses
     rows = {k: (int(a), int(b), int(c)) for k, a, b, c in re.findall(r"^(K_[A-Z0-9_]+)\s+(\d+)\s+(\d+)\s+(\d+)", r.stdout, re.M)}
@@ -37,3 +37,17 @@ def test_checked_build_finds_no_out_of_bounds_access(gpu):
                  "K_RCAS_TILE", "K_TILE_LIST", "K_TILE_REC", "K_SPAN_REC", "K_BIL_X", "K_BIL_Y", "K_NIS_COEF", "K_TIE_LIST"):
         assert rows[kind][0] > 0, "no checked access of kind %s: a kernel family did not run" % kind
         assert rows[kind][1] == 0, kind
+
+
+def test_fuzz_seeds_pass_against_the_checked_build(gpu):
+    """The fuzz tests THEMSELVES (tests/test_gpu_fuzz.py: oracle parity on random sizes / scales / masks / pitches / formats, ctx life-cycle
+    stress) on 120 fresh seeds against ab/bounds.so: every instance must pass its parity asserts -- a checked access that is wrongly flagged is
+    redirected to the plane base and corrupts the checked build's pixels, which is how the checker's one false positive was found (a 3-element
+    vector load counted as 16 bytes) -- and the device counters must show 0 out-of-bounds accesses at the end."""
+    lib = variant("bounds", "-DOVRFSR_BOUNDS")
+    env = dict(os.environ, OVRFSR_LIB=lib, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "debug", "fuzz_campaign.py"), "170000", "120"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    m = re.search(r"seeds 170000\.\.170119: (\d+) failures", r.stdout)
+    assert m and int(m.group(1)) == 0, (r.stdout[-2500:], r.stderr[-500:])
+    m = re.search(r"checked build: (\d+) checked accesses, (\d+) OUT OF BOUNDS, (\d+) declared-pad accesses", r.stdout)
+    assert m and int(m.group(1)) > 1e8 and int(m.group(2)) == 0, r.stdout[-600:]

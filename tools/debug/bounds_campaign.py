@@ -221,7 +221,7 @@ def fuzz_seeds():
                 one("fuzz-nis[%d] %dx%d->%dx%d r%.2f %s %s" % (seed, iw, ih, ow, oh, radius, of, "strict" if prec == STRICT else "product"), img8, ow, oh,
                     out_fmt=of, pad_in=pad_in, eye=eye, use_nis=1, radius=radius, proj_centre=proj, debug_mode=debug, sharpness=sharp, precision=prec)
             one("fuzz-nis[%d] sharpen" % seed, img8, iw, ih, pad_in=pad_in, eye=eye, use_nis=1, radius=radius, proj_centre=proj, debug_mode=debug, sharpness=sharp, precision=prec)
-    for seed in range(16):
+    for seed in range(240):   # (the suite runs 16 of these; the rest widen the campaign: widths of 32 k + 1 texels with a mask need many draws)
         rng = np.random.default_rng(3000 + seed)
         iw, ih = int(rng.integers(20, 330)), int(rng.integers(20, 330))
         s = float(rng.choice([0.5, 0.501, 0.67, 0.75, 0.77, 0.9, 0.99, rng.uniform(0.5, 1.0), 1.15]))
@@ -241,10 +241,15 @@ def fuzz_seeds():
 def ragged():
     shapes = [(1, 1, 2, 2), (1, 1, 1, 1), (2, 3, 3, 5), (5, 4, 7, 6), (16, 16, 21, 21), (16, 16, 32, 32), (12, 12, 16, 16), (24, 24, 32, 32), (24, 24, 33, 33),
               (31, 17, 33, 18), (33, 17, 64, 33), (47, 13, 63, 17), (13, 47, 17, 63), (96, 80, 128, 107), (100, 100, 133, 133), (64, 64, 65, 65),
-              (200, 9, 267, 12), (9, 200, 12, 267), (120, 100, 100, 84), (50, 60, 25, 30), (300, 200, 301, 201), (255, 255, 340, 340), (128, 128, 256, 256)]
+              (200, 9, 267, 12), (9, 200, 12, 267), (120, 100, 100, 84), (50, 60, 25, 30), (300, 200, 301, 201), (255, 255, 340, 340), (128, 128, 256, 256),
+              # output widths of 32 k + 1: the unchecked 12-byte row loads of rcas_column4 end flush with the row (the checker's own false positive of
+              # round 6 -- a 3-vector is 16 bytes to sizeof, 12 to the load -- was found on 49x187 -> 97x373)
+              (49, 187, 97, 373), (33, 40, 65, 80), (97, 97, 129, 129), (65, 33, 129, 65),
+              # a single tile row of odd height: the discarded second pixel of the last row pair (found by fuzz seed 162312 under the checked build)
+              (165, 32, 143, 27), (60, 40, 45, 29), (64, 24, 85, 31), (80, 20, 107, 27), (40, 23, 80, 31)]
     for i, (iw, ih, ow, oh) in enumerate(shapes):
         img8 = [synth.structured_u8, synth.random_u8, synth.extremes_u8][i % 3](iw, ih, 70 + i)
-        for radius in (2.0, 0.6, 0.2):
+        for radius in (2.0, 0.84, 0.7, 0.6, 0.2):
             fsr_forms("ragged %dx%d->%dx%d r%.1f" % (iw, ih, ow, oh, radius), img8, ow, oh, radius, (0.45, 0.55, 0.52, 0.47), i & 1, (i >> 1) & 1, 0.9, i % 4, (i + 1) % 3)
             if iw <= ow <= 2 * iw and ih <= oh <= 2 * ih:
                 for prec in (FP32, STRICT):
