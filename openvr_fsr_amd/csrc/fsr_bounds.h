@@ -178,6 +178,21 @@ template <typename T> __device__ __forceinline__ ptr<T> carve(T *base, unsigned 
     return r;
 }
 template <typename T> __device__ __forceinline__ T *raw(const ptr<T> &s) { return s.p; }
+
+// LDS POISON.  A workgroup's LDS holds whatever the previous workgroup on that CU left there; several kernels read cells they never stage
+// (the declared pads above; border columns of the analysis sweep; planes a branch did not fill) on the argument that the value never reaches a
+// stored pixel.  Checked builds make that argument testable: every byte of the launch's dynamic LDS and of every static LDS array is overwritten
+// with 0xff (as float: a NaN; as a list index: 65535, far outside every plane) by the whole workgroup before the kernel's first own write.  If a
+// stored pixel depended on an unstaged cell it would now be NaN / garbage DETERMINISTICALLY, and the parity tests, which also run against the
+// checked build (tests/test_gpu_bounds.py, tests/debug/fuzz_campaign.py), would fail.  Must be called in workgroup-uniform control flow.
+__device__ __forceinline__ void poison(void *base, unsigned long long bytes)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(base);
+    for (unsigned long long i = threadIdx.x; i < bytes / 4; i += blockDim.x) w[i] = 0xffffffffu;
+    unsigned char *b = reinterpret_cast<unsigned char *>(base);
+    for (unsigned long long i = (bytes & ~3ull) + threadIdx.x; i < bytes; i += blockDim.x) b[i] = 0xffu;
+    __syncthreads();
+}
 } // namespace ovrfsr_chk
 
 #define OVRFSR_PTR(T) ovrfsr_chk::ptr<T>                                   /* a pointer variable / parameter */
@@ -192,7 +207,8 @@ template <typename T> __device__ __forceinline__ T *raw(const ptr<T> &s) { retur
 #define OVRFSR_AT(T, e) ovrfsr_chk::at<T>(e)                               /* raw T* of one validated access (under-aligned vector typedefs) */
 #define OVRFSR_AT_N(T, bytes, e) ovrfsr_chk::at_n<T, bytes>(e)             /* ... of `bytes` bytes (3-element vectors: 12, not sizeof = 16) */
 #define OVRFSR_RAW(e) ovrfsr_chk::raw(e)                                   /* the unchecked pointer (to carve the next plane from) */
-#define OVRFSR_LDS_ARRAY(T, name, n, kind) __shared__ T name##_lds[n]; const ovrfsr_chk::ptr<T> name(name##_lds, (n), 0, ovrfsr_chk::kind)
+#define OVRFSR_LDS_ARRAY(T, name, n, kind) __shared__ T name##_lds[n]; ovrfsr_chk::poison(name##_lds, sizeof(T) * (n)); const ovrfsr_chk::ptr<T> name(name##_lds, (n), 0, ovrfsr_chk::kind)
+#define OVRFSR_LDS_POISON(smem, ldsBytes) ovrfsr_chk::poison((smem), (ldsBytes))   /* the launch's dynamic LDS, at kernel start */
 #else
 #define OVRFSR_PTR(T) T *
 #define OVRFSR_PTR_R(T) T *__restrict__
@@ -207,4 +223,5 @@ template <typename T> __device__ __forceinline__ T *raw(const ptr<T> &s) { retur
 #define OVRFSR_AT_N(T, bytes, e) reinterpret_cast<T *>(e)
 #define OVRFSR_RAW(e) (e)
 #define OVRFSR_LDS_ARRAY(T, name, n, kind) __shared__ T name[n]
+#define OVRFSR_LDS_POISON(smem, ldsBytes)
 #endif
