@@ -5,10 +5,13 @@
  *   gcc -std=c11 -O2 -D__HIP_PLATFORM_AMD__ examples/headless.c -Iinclude -I/opt/rocm/include -Lopenvr_fsr_amd -lopenvr_fsr_amd \
  *       -L/opt/rocm/lib -lamdhip64 -lm -Wl,-rpath,'$ORIGIN/../openvr_fsr_amd' -Wl,-rpath,/opt/rocm/lib -o examples/headless
  *   (plain gcc: the only HIP the caller needs is hipMalloc/hipMemcpy for its own buffers; __graft_entry__.build() does this)
- *   examples/headless [openvr_mod.cfg | -] [out.ppm | out.dds] [--pair]
+ *   examples/headless [openvr_mod.cfg | -] [out.ppm | out.dds] [--pair | --pair-rl]
  * A capture path ending in .dds is written with ovrfsr_save_dds (the reference's F7 container), anything else as a PPM.  --pair runs the same
- * frames through cfg.pair_submit: the LEFT apply only records, the RIGHT apply launches both eyes as one batch of two -- the
- * left eye's ctx-owned image is complete once the RIGHT call has returned, and the two eyes must produce the same checksum as without it.
+ * frames through cfg.pair_submit: the apply of a frame's FIRST eye only records (ovrfsr_pair_pending() == 1: a Submit detour would hold that
+ * eye's forwarded Submit back), the apply of the other eye launches both as one batch of two -- the first eye's ctx-owned image
+ * is complete once the second call has returned, and the right eye must produce the same checksum as without pairing.  --pair-rl submits the
+ * right eye first, as some games do (ABI 5: pairing is by arrival order).  Each eye has its own input texture (one texture submitted for both
+ * eyes is never paired).
  */
 #include <hip/hip_runtime_api.h>
 #include <math.h>
@@ -35,8 +38,11 @@ int main(int argc, char **argv)
         cfg.debug_mode = 1; /* for ovrfsr_last_gpu_time_ms */
     }
     cfg.out_width = 2244; cfg.out_height = 2492;
-    int pair = 0;
-    for (int i = 1; i < argc; ++i) if (!strcmp(argv[i], "--pair")) pair = 1;
+    int pair = 0, right_first = 0;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--pair")) pair = 1;
+        if (!strcmp(argv[i], "--pair-rl")) pair = right_first = 1;
+    }
     cfg.pair_submit = pair;
 
     uint8_t *h = (uint8_t *)malloc((size_t)inW * inH * 4);
@@ -48,24 +54,34 @@ int main(int argc, char **argv)
             p[2] = (uint8_t)((x + y) & 255);
             p[3] = 255;
         }
-    void *d_in = NULL;
+    void *d_in = NULL, *d_in_right = NULL; /* one texture per eye (the same content: the checksum below does not depend on the mode) */
     CHECK_HIP(hipMalloc(&d_in, (size_t)inW * inH * 4));
     CHECK_HIP(hipMemcpy(d_in, h, (size_t)inW * inH * 4, hipMemcpyHostToDevice));
+    CHECK_HIP(hipMalloc(&d_in_right, (size_t)inW * inH * 4));
+    CHECK_HIP(hipMemcpy(d_in_right, h, (size_t)inW * inH * 4, hipMemcpyHostToDevice));
 
     ovrfsr_ctx *ctx = NULL;
     int rc = ovrfsr_create(0, &cfg, &ctx);
     if (rc != OVRFSR_OK) { fprintf(stderr, "ovrfsr_create failed: %d\n", rc); return 1; }
-    ovrfsr_image in = { d_in, inW, inH, inW * 4, OVRFSR_FORMAT_RGBA8_UNORM };
+    ovrfsr_image right_out = { NULL, 0, 0, 0, 0 };
     for (int rep = 0; rep < 3; ++rep)
-        for (int eye = 0; eye < 2; ++eye) {
+        for (int k = 0; k < 2; ++k) {
+            const int eye = right_first ? 1 - k : k;
+            ovrfsr_image in = { eye ? d_in_right : d_in, inW, inH, inW * 4, OVRFSR_FORMAT_RGBA8_UNORM };
             ovrfsr_image out = { NULL, 0, 0, 0, 0 }; /* ctx-owned output, as the reference swaps Texture_t::handle */
             rc = ovrfsr_apply(ctx, eye, &in, NULL, &out, NULL);
             if (rc != OVRFSR_OK) { fprintf(stderr, "ovrfsr_apply: %d (%s)\n", rc, ovrfsr_last_error(ctx)); return 1; }
+            if (eye == 1) right_out = out;
+            if (ovrfsr_pair_pending(ctx)) { /* recorded only: nothing launched yet; a detour holds this eye's Submit until the next call returns */
+                printf("eye %d: recorded (pair_submit), result will be at %ux%u\n", eye, out.width, out.height);
+                continue;
+            }
             float ms = 0.f;
             if (ovrfsr_last_gpu_time_ms(ctx, &ms) == OVRFSR_OK)
-                printf("eye %d: %ux%u -> %ux%u  %s  %.3f ms on the GPU\n", eye, inW, inH, out.width, out.height,
-                       cfg.use_nis ? "NIS" : "EASU+RCAS", ms);
-            if (rep == 2 && eye == 1) { /* a checksum of the right eye's result: the same with and without --pair */
+                printf("eye %d: %ux%u -> %ux%u  %s  %.3f ms on the GPU%s\n", eye, inW, inH, out.width, out.height,
+                       cfg.use_nis ? "NIS" : "EASU+RCAS", ms, pair ? " (both eyes, one batch of two)" : "");
+            if (rep == 2 && k == 1) { /* a checksum of the right eye's result: the same in every mode */
+                out = right_out;
                 const size_t nb = (size_t)out.pitch_bytes * out.height;
                 uint8_t *o = (uint8_t *)malloc(nb);
                 CHECK_HIP(hipMemcpy(o, out.data, nb, hipMemcpyDeviceToHost));
@@ -74,7 +90,7 @@ int main(int argc, char **argv)
                 free(o);
                 printf("right eye checksum %016llx%s\n", (unsigned long long)hsh, pair ? " (pair_submit)" : "");
             }
-            if (rep == 2 && eye == 1 && argc > 2 && strcmp(argv[2], "--pair") != 0) {
+            if (rep == 2 && k == 1 && argc > 2 && strncmp(argv[2], "--pair", 6) != 0) {
                 const size_t L = strlen(argv[2]);
                 const int dds = L > 4 && !strcmp(argv[2] + L - 4, ".dds");
                 rc = dds ? ovrfsr_save_dds(&out, argv[2], NULL) : ovrfsr_save_ppm(&out, argv[2], NULL);
@@ -83,6 +99,7 @@ int main(int argc, char **argv)
         }
     ovrfsr_destroy(ctx);
     CHECK_HIP(hipFree(d_in));
+    CHECK_HIP(hipFree(d_in_right));
     free(h);
     return 0;
 }

@@ -680,6 +680,13 @@ def test_plain_c_caller(gpu, tmp_path):
     cs = [l.split()[3] for l in r.stdout.splitlines() if l.startswith("right eye checksum")]
     cs2 = [l.split()[3] for l in r2.stdout.splitlines() if l.startswith("right eye checksum")]
     assert len(cs) == 1 and cs == cs2 and "(pair_submit)" in r2.stdout
+    # the pair really forms (each eye has its own texture): three LEFT applies recorded, three RIGHT applies launching both -- ovrfsr_pair_pending
+    assert r2.stdout.count("eye 0: recorded (pair_submit)") == 3 and r2.stdout.count("(both eyes, one batch of two)") == 3, r2.stdout
+    # round 6 (ABI 5): a game that submits the right eye first pairs as well, same pixels
+    r3 = subprocess.run([exe, "-", str(tmp_path / "eye_rl.dds"), "--pair-rl"], capture_output=True, text=True, timeout=120)
+    assert r3.returncode == 0, r3.stderr
+    cs3 = [l.split()[3] for l in r3.stdout.splitlines() if l.startswith("right eye checksum")]
+    assert cs3 == cs and r3.stdout.count("eye 1: recorded (pair_submit)") == 3 and r3.stdout.count("eye 0: recorded") == 0, r3.stdout
     d = open(dds, "rb").read()
     assert d[:4] == b"DDS " and len(d) == 148 + 2244 * 2492 * 4 and np.array_equal(np.frombuffer(d[148:], np.uint8).reshape(2492, 2244, 4)[..., :3].reshape(-1), px)
 
