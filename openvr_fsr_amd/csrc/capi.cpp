@@ -80,6 +80,8 @@ OVRFSR_API int ovrfsr_debug_bounds(unsigned long long *counts, int n, int reset)
     return ovrfsr::bounds_read_nis(counts, reset != 0) == hipSuccess ? OVRFSR_OK : OVRFSR_ERR_HIP;
 }
 OVRFSR_API int ovrfsr_debug_bounds_selftest(void) { return ovrfsr::bounds_selftest() == hipSuccess ? OVRFSR_OK : OVRFSR_ERR_HIP; }
+// fault injection (checked builds only): the nth device allocation / stream / event creation of the launch manager from now on fails, once; 0 disarms
+OVRFSR_API void ovrfsr_debug_fail_resource(int nth) { ovrfsr::debug_fail_resource(nth); }
 #endif
 
 OVRFSR_API int ovrfsr_pair_pending(const ovrfsr_ctx *ctx) { return ctx && ctx->pp && ctx->pp->PairPending() ? 1 : 0; }

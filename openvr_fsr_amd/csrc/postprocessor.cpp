@@ -29,6 +29,26 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Every device allocation and every stream / event the launch manager creates goes through these.  Product build: the HIP call.  Checked builds
+// (-DOVRFSR_BOUNDS): FAULT INJECTION -- ovrfsr_debug_fail_resource(n) arms a countdown and the n-th creation from then on fails with
+// hipErrorOutOfMemory, once; tools/debug/fault_campaign.py walks n over every configuration and asserts what the header promises about failures
+// (status codes, outputs untouched, a failed (re)build disables the ctx until reset: PostProcessor.cpp:145-152).  The reference has no fault
+// injection; its failure handling has never been exercised either.
+#ifdef OVRFSR_BOUNDS
+static int g_fail_countdown = 0; // 0 = disarmed
+void debug_fail_resource(int nth) { g_fail_countdown = nth > 0 ? nth : 0; }
+static bool inject_failure() { return g_fail_countdown > 0 && --g_fail_countdown == 0; }
+#else
+static inline bool inject_failure() { return false; }
+#endif
+static inline hipError_t dev_malloc(void **p, size_t bytes) { return inject_failure() ? hipErrorOutOfMemory : hipMalloc(p, bytes); }
+static inline hipError_t event_create(hipEvent_t *e, unsigned flags) { return inject_failure() ? hipErrorOutOfMemory : hipEventCreateWithFlags(e, flags); }
+static inline hipError_t stream_create(hipStream_t *s, int prioMode, int least, int greatest)
+{
+    if (inject_failure()) return hipErrorOutOfMemory;
+    return prioMode == 0 ? hipStreamCreateWithFlags(s, hipStreamNonBlocking) : hipStreamCreateWithPriority(s, hipStreamNonBlocking, prioMode == 1 ? least : greatest);
+}
+
 // a*b+c with two roundings, identical to the kernels' mad_unfused (separate statements)
 static inline float mad2(float a, float b, float c)
 {
@@ -60,13 +80,16 @@ hipStream_t PostProcessor::Fork(hipStream_t user, bool overlap)
         static const int prio = [] { const char *e = std::getenv("OVRFSR_AUX_PRIORITY"); return !e ? 1 : e[0] == 'd' ? 0 : e[0] == 'h' ? 2 : 1; }();
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const hipError_t ce = prio == 0 ? hipStreamCreateWithFlags(&auxStream_, hipStreamNonBlocking)
-                                        : hipStreamCreateWithPriority(&auxStream_, hipStreamNonBlocking, prio == 1 ? least : greatest);
+        const hipError_t ce = stream_create(&auxStream_, prio, least, greatest);
         if (ce != hipSuccess ||
-            hipEventCreateWithFlags(&evFork_, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&evJoin_, hipEventDisableTiming) != hipSuccess) {
+            event_create(&evFork_, hipEventDisableTiming) != hipSuccess ||
+            event_create(&evJoin_, hipEventDisableTiming) != hipSuccess) {
+            // no second stream: run everything in order on the caller's stream (and do not keep half of the set: a later Fork would use it)
+            if (ce == hipSuccess && auxStream_) (void)hipStreamDestroy(auxStream_);
+            if (evFork_) { (void)hipEventDestroy(evFork_); evFork_ = nullptr; }
+            if (evJoin_) { (void)hipEventDestroy(evJoin_); evJoin_ = nullptr; }
             auxStream_ = nullptr;
-            return user; // no second stream: run everything in order on the caller's stream
+            return user;
         }
     }
     (void)hipEventRecord(evFork_, user);
@@ -178,7 +201,7 @@ int PostProcessor::EnsureBuffer(void **buf, size_t *have, size_t need)
     if (*buf) (void)hipFree(*buf);
     *buf = nullptr;
     *have = 0;
-    hipError_t e = hipMalloc(buf, need);
+    hipError_t e = dev_malloc(buf, need);
     if (e != hipSuccess) return Fail(OVRFSR_ERR_OUT_OF_MEMORY, std::string("hipMalloc: ") + hipGetErrorString(e));
     *have = need;
     return OVRFSR_OK;
@@ -334,7 +357,7 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
         outsideCols_ = span(taps.data(), ow, 32);
         outsideRows_[0] = span(taps.data() + bilYOff_, oh, 32);
         outsideRows_[1] = span(taps.data() + bilYOff_, oh, 24);
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&bilinDev_), taps.size() * sizeof(BilinTap));
+        hipError_t e = dev_malloc(reinterpret_cast<void **>(&bilinDev_), taps.size() * sizeof(BilinTap));
         if (e == hipSuccess) e = hipMemcpy(bilinDev_, taps.data(), taps.size() * sizeof(BilinTap), hipMemcpyHostToDevice);
         if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("bilinear tap tables: ") + hipGetErrorString(e));
     }
@@ -371,9 +394,11 @@ int PostProcessor::PrepareResources(const ovrfsr_image &submitted)
             return Fail(OVRFSR_ERR_UNSUPPORTED, "fused kernel: tile footprint does not fit LDS at this scale");
         useFused_ = true;
     }
-    if (cfg_.debug_mode && !queries_[0].start) {
+    if (cfg_.debug_mode) {
+        // every slot is checked on its own: a creation that failed half-way through the ring (found by fault injection, round 6: slot 0 existed,
+        // a later one did not, and the rebuild after reset skipped the whole ring -- hipEventRecord on a null event) is completed by the next build
         for (ProfileQuery &q : queries_)
-            if (hipEventCreate(&q.start) != hipSuccess || hipEventCreate(&q.end) != hipSuccess)
+            if ((!q.start && event_create(&q.start, hipEventDefault) != hipSuccess) || (!q.end && event_create(&q.end, hipEventDefault) != hipSuccess))
                 return Fail(OVRFSR_ERR_HIP, "hipEventCreate failed");
     }
     initialized_ = true;
@@ -486,7 +511,7 @@ int PostProcessor::PrepareTileLists(uint32_t tileW, uint32_t tileH, uint32_t gro
         }
     }
     const size_t listDwords = (lists.size() + 3) & ~(size_t)3; // the records follow the lists, 16-byte aligned
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&tileListDev_), (listDwords + recs.size() + spans.size()) * sizeof(uint32_t));
+    hipError_t e = dev_malloc(reinterpret_cast<void **>(&tileListDev_), (listDwords + recs.size() + spans.size()) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemcpy(tileListDev_, lists.data(), lists.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         tileRecDev_ = tileListDev_ + listDwords;
@@ -524,7 +549,7 @@ int PostProcessor::PrepareNisResources()
         if (nis_pitch(nisCellsW_) == 0 || nis_scaler_lds_bytes(nisCellsW_, nisCellsH_) > 64 * 1024)
             return Fail(OVRFSR_ERR_UNSUPPORTED, "NIS tile does not fit LDS");
     }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&nisCoefDev_), 2 * 512 * sizeof(float));
+    hipError_t e = dev_malloc(reinterpret_cast<void **>(&nisCoefDev_), 2 * 512 * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(nisCoefDev_, nis_coef_scale(), 512 * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(nisCoefDev_ + 512, nis_coef_usm(), 512 * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) return Fail(OVRFSR_ERR_HIP, std::string("NIS coefficient upload: ") + hipGetErrorString(e));
@@ -872,7 +897,7 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
     // instead of surfacing as a launch error behind the EASU pass -- found by the round-6 format sweep)
     if (outTen && doUpscale_ && doSharpen_ && IntermediateFormat() != OVRFSR_FORMAT_RGB10A2_UNORM)
         return Fail(OVRFSR_ERR_UNSUPPORTED, "RGB10A2 pipelines keep a 10-bit intermediate (quantize_intermediate = 1)");
-    const bool timing = cfg_.debug_mode && queries_[0].start;
+    const bool timing = cfg_.debug_mode && queries_[kQueryCount - 1].end; // (the ring is complete: slots are created in order)
     if (timing) (void)hipEventRecord(queries_[currentQuery_].start, stream);
     int rc = OVRFSR_OK;
     if (useSorted_) {

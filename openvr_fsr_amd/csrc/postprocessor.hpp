@@ -18,6 +18,9 @@ void rcas_con(uint32_t con[4], float stops);
 void mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t outW, uint32_t outH, const float proj[4],
                     float cfgRadius, int onlyOneEye, int eye);
 uint32_t classify_mask(const uint32_t centre[4], uint32_t r2, uint32_t outW, uint32_t outH, uint32_t gw, uint32_t gh);
+#ifdef OVRFSR_BOUNDS
+void debug_fail_resource(int nth); // checked builds: the nth device allocation / stream / event creation from now on fails, once (postprocessor.cpp)
+#endif
 
 class PostProcessor {
 public:

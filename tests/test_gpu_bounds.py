@@ -51,3 +51,17 @@ def test_fuzz_seeds_pass_against_the_checked_build(gpu):
     assert m and int(m.group(1)) == 0, (r.stdout[-2500:], r.stderr[-500:])
     m = re.search(r"checked build: (\d+) checked accesses, (\d+) OUT OF BOUNDS, (\d+) declared-pad accesses", r.stdout)
     assert m and int(m.group(1)) > 1e8 and int(m.group(2)) == 0, r.stdout[-600:]
+
+
+def test_injected_resource_failures_leave_outputs_untouched(gpu):
+    """FAULT INJECTION (failure detection / recovery: "no fault injection" in the reference).  The checked build can make
+    the n-th device allocation / stream / event creation of the launch manager fail; tools/debug/fault_campaign.py walks n over ten pipeline
+    configurations and checks the header's promises: a status and an error text, the caller's output image untouched, a failed (re)build
+    leaves the ctx DISABLED (PostProcessor.cpp:145-152) and the next apply touches nothing, failures the library can absorb (no auxiliary
+    stream: in-order launches) still give correct pixels, and reset restores a ctx that produces exactly the un-failed result."""
+    lib = variant("bounds", "-DOVRFSR_BOUNDS")
+    env = dict(os.environ, OVRFSR_LIB=lib, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "debug", "fault_campaign.py")], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    m = re.search(r"TOTAL (\d+) injected failures over (\d+) configurations, (\d+) violations", r.stdout)
+    assert m, (r.stdout[-1500:], r.stderr[-800:])
+    assert r.returncode == 0 and int(m.group(3)) == 0 and int(m.group(1)) >= 20, r.stdout[-2500:]
