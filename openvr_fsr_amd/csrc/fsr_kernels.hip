@@ -312,10 +312,14 @@ __global__ __launch_bounds__(256) void bgra_to_rgba_kernel(const uint8_t *__rest
 {
     const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
     if (x >= w) return;
-    const uint32_t v = *reinterpret_cast<const uint32_t *>(src + (size_t)img * srcStride + (size_t)y * srcPitch + (size_t)x * 4);
+    // (checked builds: image `img` of the submission, and the tight copy of the whole batch as one image of gridDim.z * h rows, through the
+    // accessors of fsr_bounds.h; the address expressions are the ones the product build has always had)
+    OVRFSR_PTR(const uint8_t) s = OVRFSR_IMAGE(const uint8_t, src + (size_t)img * srcStride, srcPitch, (int)w, (int)h, 4u, K_IMAGE_IN);
+    OVRFSR_PTR(uint8_t) d = OVRFSR_IMAGE(uint8_t, dst, w * 4u, (int)w, (int)(h * gridDim.z), 4u, K_IMAGE_OUT);
+    const uint32_t v = *OVRFSR_AT(const uint32_t, s + (size_t)y * srcPitch + (size_t)x * 4);
     // byte order in memory B,G,R,A -> R,G,B,A: swap bytes 0 and 2
     const uint32_t o = (v & 0xff00ff00u) | ((v >> 16) & 0xffu) | ((v & 0xffu) << 16);
-    *reinterpret_cast<uint32_t *>(dst + ((size_t)img * h + y) * (size_t)w * 4 + (size_t)x * 4) = o;
+    *OVRFSR_AT(uint32_t, d + ((size_t)img * h + y) * (size_t)w * 4 + (size_t)x * 4) = o;
 }
 
 hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t srcStride, uint8_t *dst, uint32_t w, uint32_t h,
