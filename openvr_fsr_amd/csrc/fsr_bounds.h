@@ -68,6 +68,13 @@ constexpr int kSlots = 3 * K_COUNT + 5;
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+// MUTATION of the checker (-DOVRFSR_BOUNDS -DOVRFSR_BOUNDS_SHRINK=1, never a test dependency): every plane, table and image is DECLARED one
+// element / one texel column shorter than it is.  A campaign against that build must light up every kind whose last element a kernel really
+// touches -- the proof, in the kernels themselves rather than in the self-test, that each check is live (profiles/r06_bounds.txt, 1g).
+#ifndef OVRFSR_BOUNDS_SHRINK
+#define OVRFSR_BOUNDS_SHRINK 0
+#endif
+
 namespace ovrfsr_chk {
 static __device__ unsigned long long g_counts[kSlots]; // one array per translation unit (internal linkage)
 
@@ -100,8 +107,8 @@ template <typename T> struct ptr {
     __device__ __forceinline__ ptr(decltype(nullptr)) : ptr() {}
     __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
     __device__ __forceinline__ ptr(T *base, unsigned long long n, unsigned long long padN, uint32_t k)
-        : p(base), lo(reinterpret_cast<const char *>(base)), hi(reinterpret_cast<const char *>(base) + n * sizeof(T)),
-          padhi(reinterpret_cast<const char *>(base) + (n + padN) * sizeof(T)), kind(k), rowPitch(0), rowBytes(0) {}
+        : p(base), lo(reinterpret_cast<const char *>(base)), hi(reinterpret_cast<const char *>(base) + (n > OVRFSR_BOUNDS_SHRINK ? n - OVRFSR_BOUNDS_SHRINK : n) * sizeof(T)),
+          padhi(reinterpret_cast<const char *>(base) + (padN ? n + padN : (n > OVRFSR_BOUNDS_SHRINK ? n - OVRFSR_BOUNDS_SHRINK : n)) * sizeof(T)), kind(k), rowPitch(0), rowBytes(0) {}
 
     // the address of an access of `bytes` bytes at q, or the plane base when q is out of bounds (counted)
     __device__ __forceinline__ const char *check(const char *q, unsigned long long bytes) const
@@ -164,7 +171,7 @@ template <typename T> __device__ __forceinline__ ptr<T> image(T *base, uint32_t 
     ptr<T> r;
     r.p = base; r.lo = reinterpret_cast<const char *>(base);
     r.hi = r.padhi = r.lo + ((unsigned long long)(h - 1) * pitch + (unsigned long long)w * texel);
-    r.kind = kind; r.rowPitch = pitch; r.rowBytes = (uint32_t)w * texel;
+    r.kind = kind; r.rowPitch = pitch; r.rowBytes = (uint32_t)(w > OVRFSR_BOUNDS_SHRINK ? w - OVRFSR_BOUNDS_SHRINK : w) * texel;
     return r;
 }
 // a plane carved from the dynamic LDS of the launch: [base, base + n + pad) must lie inside [smem, smem + ldsBytes)
