@@ -31,7 +31,7 @@ done
 make -C "$ROOT/openvr_fsr_amd/csrc" -j8 EXTRA=--offload-compress BUILD=build_z build_z/fsr_kernels.o build_z/nis_kernels.o >/dev/null
 mkdir -p "$ROOT/openvr_fsr_amd/csrc/build_asan_gcc"
 for f in postprocessor constants nis_config config_json capi; do
-    g++ -std=c++17 -O1 -g -fPIC -fvisibility=hidden -D__HIP_PLATFORM_AMD__ -I"$ROCM/include" -ffp-contract=off $SAN \
+    g++ -std=c++17 -O1 -g1 -fPIC -fvisibility=hidden -D__HIP_PLATFORM_AMD__ -I"$ROCM/include" -ffp-contract=off $SAN \
         -c "$ROOT/openvr_fsr_amd/csrc/$f.cpp" -o "$ROOT/openvr_fsr_amd/csrc/build_asan_gcc/$f.o"
 done
 ${HIPCC:-$ROCM/bin/hipcc} --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/asan_gcc.so" "$ROOT"/openvr_fsr_amd/csrc/build_asan_gcc/*.o \
