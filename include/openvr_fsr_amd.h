@@ -72,10 +72,11 @@ typedef enum ovrfsr_format {
  *                follows the largest tap, not the output), for values >= xmin = 0.25 / 0.5 derived from the sharpness (a flipped half-ulp
  *                below xmin stays under 1e-3 behind RCAS's largest gain) -- is re-resolved in the reference's operator order (near-tie
  *                guard).  This is AUDITED, not derived: an audit build of the same kernels (-DOVRFSR_TIE_AUDIT) re-resolves every
- *                pixel in reference order on the device and counts the unlisted pixels whose stored value differs -- 0 in 8.9e9 pixels over
- *                every configuration, structured / random / extreme content, RGBA16F content up to 40x the unit range, and the candidates of
- *                a directed search that maximises the distance between the two evaluations; the largest distance met is 3.0e-4 byte, 0.15 of
- *                the band (profiles/r05_tie_audit.txt, tests/test_gpu_adversarial.py).  A first-order worst-case bound of that distance is
+ *                pixel in reference order on the device and counts the unlisted pixels whose stored value differs -- 0 in 1.2e12 pixels over
+ *                every configuration, structured / random / extreme / natural content, RGBA16F content up to 40x the unit range, and the
+ *                candidates of a directed search that maximises the distance between the two evaluations; the largest distance met is
+ *                3.5e-4 byte, 0.18 of the band (profiles/r05_tie_audit.txt, profiles/r06_tie_audit_campaigns.txt,
+ *                tests/test_gpu_adversarial.py).  A first-order worst-case bound of that distance is
  *                two orders of magnitude above the band (same file, section 5): the filter's one ill-conditioned step, the direction blend, is
  *                evaluated in the reference's order for that reason, the rest is rounding noise that no norm bound captures.  A violation,
  *                should one exist, is one LSB (one half-ulp) of one intermediate pixel.  Float outputs differ by <= 3e-6, UNORM8 pipeline

@@ -8,7 +8,8 @@ the pixels that were NOT listed by the guard and whose stored value differs from
 It also records the largest |product - strict| it met (bytes of the UNORM8 domain; half spacings for half stores): the band is 2^-9 byte /
 2^-6 spacing.
 
-    OVRFSR_LIB=$PWD/ab/audit.so python tools/debug/tie_audit.py [scale=1.0]      (GPU; `scale` multiplies the images per configuration)
+    OVRFSR_LIB=$PWD/ab/audit.so python tools/debug/tie_audit.py [scale=1.0] [seed_offset=0]      (GPU; `scale` multiplies the images per
+    configuration, `seed_offset` moves every generator seed: a further campaign on content no earlier one saw)
 
 Content: natural images (round 6: tests/golden/natural_*.npz, mirror-tiled), the bench's structured and uniform-random generators, 0 / 255-heavy images, and a mosaic of 8x8-texel patches of the families the
 adversarial search (tools/debug/easu_err_search.py) mutates -- two-level edges at random angles, ramps with noise, near-constant patches with
@@ -118,7 +119,7 @@ def main():
             total[key] = max(total[key], c[key])
 
     t0 = time.time()
-    seed = 0x5EED0000
+    seed = 0x5EED0000 + (int(sys.argv[2], 0) if len(sys.argv) > 2 else 0)
     C2 = (1683, 1869, 2244, 2492)
     for content in ("structured", "random", "extremes", "mosaic", "natural"):
         for rep in range(2):
