@@ -7,7 +7,8 @@ knows the extent of what it points into (including the DECLARED pads: allocated 
 outside is counted per kind instead of faulting; the claim is: 0 out-of-bounds accesses, and pad accesses only of the kinds the design
 declares (the luma rows behind EASU's 4-rows-per-lane analysis sweep; the tap-table quads behind the last output column).
 
-    OVRFSR_LIB=$PWD/ab/bounds.so python tools/debug/bounds_campaign.py [--full]      (GPU)
+    OVRFSR_LIB=$PWD/ab/bounds.so python tools/debug/bounds_campaign.py [--full | --quick] [--seed-offset N]      (GPU; --seed-offset: only the
+    random-shape generators, on draws no earlier campaign saw)
 
 Campaign: (0) the self-test launch -- every kind of violation once, exact counts expected: a zero below means "nothing out of bounds",
 not "nothing checked"; (1) the seeds of tests/test_gpu_fuzz.py (random sizes 5..330, scales 0.5..1.15, masks, projection centres, padded
@@ -191,22 +192,25 @@ def fsr_forms(tag, img8, ow, oh, radius, proj, eye, debug, sharp, pad_in, pad_ou
             one("%s %s %s" % (tag, name, "strict" if prec == STRICT else "product"), img8, ow, oh, pad_in=pad_in, pad_out=pad_out, eye=eye, **kw)
 
 
+SEED_OFF = 0   # --seed-offset N: the same generators on draws no earlier campaign saw (N a multiple of 10 000 keeps the three families apart)
+
+
 def fuzz_seeds():
     """the instance generators of tests/test_gpu_fuzz.py, same seeds"""
     for seed in range(24):
-        rng = np.random.default_rng(1000 + seed)
+        rng = np.random.default_rng(1000 + seed + SEED_OFF)
         iw, ih = int(rng.integers(5, 150)), int(rng.integers(5, 150))
         s = float(rng.choice([0.5, 0.59, 0.67, 0.75, 0.77, 0.9, 0.97, rng.uniform(0.5, 1.0)]))
         ow, oh = max(iw + 1, int(iw / s)), max(ih + 1, int(ih / s))
         radius = float(rng.choice([2.0, 2.0, rng.uniform(0.15, 1.3)]))
         proj = tuple(float(x) for x in rng.uniform(0.25, 0.75, 4))
         eye, debug, sharp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(0, 1))
-        img8 = [synth.structured_u8, synth.random_u8, synth.extremes_u8][seed % 3](iw, ih, seed)
+        img8 = [synth.structured_u8, synth.random_u8, synth.extremes_u8][seed % 3](iw, ih, seed + SEED_OFF)
         pad_in, pad_out = int(rng.integers(0, 9)), int(rng.integers(0, 9))
         fsr_forms("fuzz-fsr[%d] %dx%d->%dx%d r%.2f" % (seed, iw, ih, ow, oh, radius), img8, ow, oh, radius, proj, eye, debug, sharp, pad_in, pad_out)
         one("fuzz-fsr[%d] rcas-only" % seed, img8, iw, ih, pad_in=pad_in, pad_out=pad_out, eye=eye, radius=radius, proj_centre=proj, debug_mode=debug, stage_mask=2)
     for seed in range(12):
-        rng = np.random.default_rng(2000 + seed)
+        rng = np.random.default_rng(2000 + seed + SEED_OFF)
         iw, ih = int(rng.integers(5, 150)), int(rng.integers(5, 150))
         s = float(rng.choice([0.5, 0.59, 0.67, 0.75, 0.77, 0.9, 0.97, rng.uniform(0.5, 1.0)]))
         ow, oh = max(iw + 1, int(iw / s)), max(ih + 1, int(ih / s))
@@ -214,7 +218,7 @@ def fuzz_seeds():
         proj = tuple(float(x) for x in rng.uniform(0.25, 0.75, 4))
         eye, debug, sharp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(0, 1))
         ow, oh = min(ow, 2 * iw), min(oh, 2 * ih)
-        img8 = [synth.structured_u8, synth.random_u8, synth.extremes_u8][seed % 3](iw, ih, seed)
+        img8 = [synth.structured_u8, synth.random_u8, synth.extremes_u8][seed % 3](iw, ih, seed + SEED_OFF)
         pad_in = int(rng.integers(0, 9))
         for prec in (FP32, STRICT):
             for of in ("u8", "f32"):
@@ -222,7 +226,7 @@ def fuzz_seeds():
                     out_fmt=of, pad_in=pad_in, eye=eye, use_nis=1, radius=radius, proj_centre=proj, debug_mode=debug, sharpness=sharp, precision=prec)
             one("fuzz-nis[%d] sharpen" % seed, img8, iw, ih, pad_in=pad_in, eye=eye, use_nis=1, radius=radius, proj_centre=proj, debug_mode=debug, sharpness=sharp, precision=prec)
     for seed in range(240):   # (the suite runs 16 of these; the rest widen the campaign: widths of 32 k + 1 texels with a mask need many draws)
-        rng = np.random.default_rng(3000 + seed)
+        rng = np.random.default_rng(3000 + seed + SEED_OFF)
         iw, ih = int(rng.integers(20, 330)), int(rng.integers(20, 330))
         s = float(rng.choice([0.5, 0.501, 0.67, 0.75, 0.77, 0.9, 0.99, rng.uniform(0.5, 1.0), 1.15]))
         ow, oh = max(8, int(iw / s)), max(8, int(ih / s))
@@ -231,7 +235,7 @@ def fuzz_seeds():
         radius = float(rng.uniform(0.1, 0.9))
         proj = tuple(float(x) for x in rng.uniform(0.3, 0.7, 4))
         eye, debug, sharp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), float(rng.uniform(0, 1))
-        img8 = [synth.structured_u8, synth.random_u8][seed % 2](iw, ih, seed)
+        img8 = [synth.structured_u8, synth.random_u8][seed % 2](iw, ih, seed + SEED_OFF)
         pad_in, pad_out = int(rng.integers(0, 5)), int(rng.integers(0, 5))
         fsr_forms("fuzz-masked[%d] %dx%d->%dx%d r%.2f" % (seed, iw, ih, ow, oh, radius), img8, ow, oh, radius, proj, eye, debug, sharp, pad_in, pad_out, precisions=(FP32,))
         if ow <= 2 * iw and oh <= 2 * ih and ow >= iw and oh >= ih:
@@ -365,14 +369,19 @@ def natural():
 
 
 def main():
+    global SEED_OFF
     full = "--full" in sys.argv
     quick = "--quick" in sys.argv
+    if "--seed-offset" in sys.argv:   # fresh random shapes only: the other sections are deterministic
+        SEED_OFF = int(sys.argv[sys.argv.index("--seed-offset") + 1], 0)
     t0 = time.time()
     ok = selftest()
     sections = [("fuzz seeds", fuzz_seeds), ("ragged shapes", ragged), ("formats", formats), ("batches / shared / pair", batches)]
     if not quick:
         sections.append(("BASELINE C1-C5 full size", lambda: baseline(8 if full else 2)))
     sections.append(("natural content", natural))
+    if SEED_OFF:
+        sections = [("fuzz seeds + %d" % SEED_OFF, fuzz_seeds)]
     for name, fn in sections:
         before = TOTAL["launch_groups"]
         t1 = time.time()
