@@ -18,6 +18,7 @@
  *   2 NVScaler, radius 0.45           5 debug_mode (timing ring, average read back)
  *   3 fused kernel, radius 0.5        6 input size changes twice (rebuild between launches)
  *                                     7 set_config between launches (hotkey path) + reset
+ * Every thread first drives a ctx that the MAIN thread created for it (job 1's configuration) and the main thread destroys after the join.
  * Host-only entry points (config_from_json, mask_constants, nis_scaler_config, easu_con) are called from every thread between jobs.
  * Exit status 0 and one line "thread_stress: T threads x R rounds x 9 jobs: all checksums equal the serial run" on success. */
 #include <hip/hip_runtime_api.h>
@@ -58,25 +59,8 @@ static uint64_t fnv1a(uint64_t h, const uint8_t *p, size_t n)
 typedef struct { char text[256]; } err_t;
 #define CHECK(cond, ...) do { if (!(cond)) { snprintf(err->text, sizeof err->text, __VA_ARGS__); goto done; } } while (0)
 
-/* one job, start to finish; returns 0 and the checksum of everything it downloaded, or -1 and err->text */
-static int run_job(int job, uint32_t seed, uint64_t *sum, err_t *err)
+static ovrfsr_config job_config(int job)
 {
-    int rc = -1;
-    const size_t in_bytes = (size_t)IN_W * IN_H * 4, in2_bytes = (size_t)IN2_W * IN2_H * 4, out_bytes = (size_t)OUT_W * OUT_H * 4;
-    void *d_in = NULL, *d_in2 = NULL, *d_out = NULL;
-    hipStream_t stream = NULL;
-    ovrfsr_ctx *ctx = NULL;
-    uint8_t *h = (uint8_t *)malloc(2 * in_bytes > 2 * out_bytes ? 2 * in_bytes : 2 * out_bytes);
-    uint64_t acc = 0xcbf29ce484222325ull;
-    CHECK(h, "host allocation");
-    CHECK(hipStreamCreate(&stream) == hipSuccess, "hipStreamCreate");
-    CHECK(hipMalloc(&d_in, 2 * in_bytes) == hipSuccess && hipMalloc(&d_in2, 2 * in2_bytes) == hipSuccess && hipMalloc(&d_out, 2 * out_bytes) == hipSuccess, "hipMalloc");
-    synth(h, IN_W, IN_H, seed); synth(h + in_bytes, IN_W, IN_H, seed + 1);
-    CHECK(hipMemcpy(d_in, h, 2 * in_bytes, hipMemcpyHostToDevice) == hipSuccess, "upload");
-    synth(h, IN2_W, IN2_H, seed + 2); synth(h + in2_bytes, IN2_W, IN2_H, seed + 3);
-    CHECK(hipMemcpy(d_in2, h, 2 * in2_bytes, hipMemcpyHostToDevice) == hipSuccess, "upload");
-    CHECK(hipMemset(d_out, 0, 2 * out_bytes) == hipSuccess, "memset");
-
     ovrfsr_config cfg;
     ovrfsr_config_default(&cfg);
     cfg.fsr_enabled = 1; cfg.sharpness = 0.9f; cfg.radius = 0.5f; cfg.out_width = OUT_W; cfg.out_height = OUT_H;
@@ -90,7 +74,30 @@ static int run_job(int job, uint32_t seed, uint64_t *sum, err_t *err)
     case 8: cfg.precision = OVRFSR_PRECISION_FP32_STRICT; break;
     default: break;
     }
-    CHECK(ovrfsr_create(0, &cfg, &ctx) == OVRFSR_OK, "ovrfsr_create (job %d)", job);
+    return cfg;
+}
+
+/* one job, start to finish; returns 0 and the checksum of everything it downloaded, or -1 and err->text */
+static int run_job(int job, uint32_t seed, uint64_t *sum, err_t *err, ovrfsr_ctx *given)
+{
+    int rc = -1;
+    const size_t in_bytes = (size_t)IN_W * IN_H * 4, in2_bytes = (size_t)IN2_W * IN2_H * 4, out_bytes = (size_t)OUT_W * OUT_H * 4;
+    void *d_in = NULL, *d_in2 = NULL, *d_out = NULL;
+    hipStream_t stream = NULL;
+    ovrfsr_ctx *ctx = given; /* a ctx made by ANOTHER thread (how a VR host does it: created at start-up, driven from the render thread) */
+    uint8_t *h = (uint8_t *)malloc(2 * in_bytes > 2 * out_bytes ? 2 * in_bytes : 2 * out_bytes);
+    uint64_t acc = 0xcbf29ce484222325ull;
+    CHECK(h, "host allocation");
+    CHECK(hipStreamCreate(&stream) == hipSuccess, "hipStreamCreate");
+    CHECK(hipMalloc(&d_in, 2 * in_bytes) == hipSuccess && hipMalloc(&d_in2, 2 * in2_bytes) == hipSuccess && hipMalloc(&d_out, 2 * out_bytes) == hipSuccess, "hipMalloc");
+    synth(h, IN_W, IN_H, seed); synth(h + in_bytes, IN_W, IN_H, seed + 1);
+    CHECK(hipMemcpy(d_in, h, 2 * in_bytes, hipMemcpyHostToDevice) == hipSuccess, "upload");
+    synth(h, IN2_W, IN2_H, seed + 2); synth(h + in2_bytes, IN2_W, IN2_H, seed + 3);
+    CHECK(hipMemcpy(d_in2, h, 2 * in2_bytes, hipMemcpyHostToDevice) == hipSuccess, "upload");
+    CHECK(hipMemset(d_out, 0, 2 * out_bytes) == hipSuccess, "memset");
+
+    ovrfsr_config cfg = job_config(job);
+    if (!given) CHECK(ovrfsr_create(0, &cfg, &ctx) == OVRFSR_OK, "ovrfsr_create (job %d)", job);
 
     const ovrfsr_bounds one_eye = { 0.f, 0.f, 1.f, 1.f };
     for (int it = 0; it < ITERS; ++it) {
@@ -122,7 +129,7 @@ static int run_job(int job, uint32_t seed, uint64_t *sum, err_t *err)
     *sum = acc;
     rc = 0;
 done:
-    if (ctx) ovrfsr_destroy(ctx);
+    if (ctx && !given) ovrfsr_destroy(ctx);
     if (d_in) (void)hipFree(d_in);
     if (d_in2) (void)hipFree(d_in2);
     if (d_out) (void)hipFree(d_out);
@@ -153,7 +160,7 @@ static uint64_t host_only(void)
     return acc;
 }
 
-typedef struct { int index, rounds, status; const uint64_t *ref; uint64_t host_ref; pthread_barrier_t *gate; err_t err; } worker_t;
+typedef struct { int index, rounds, status; const uint64_t *ref; uint64_t host_ref; pthread_barrier_t *gate; err_t err; ovrfsr_ctx *handed; } worker_t;
 
 static void *worker(void *arg)
 {
@@ -161,11 +168,17 @@ static void *worker(void *arg)
     w->status = 0;
     if (hipSetDevice(0) != hipSuccess) { snprintf(w->err.text, sizeof w->err.text, "hipSetDevice"); w->status = 1; }
     pthread_barrier_wait(w->gate); /* everybody starts creating ctxs at once */
+    if (!w->status && w->handed) { /* first the ctx the main thread created and handed over (job 1's configuration) */
+        uint64_t sum = 0;
+        if (run_job(1, 110u, &sum, &w->err, w->handed) != 0) w->status = 1;
+        else if (sum != w->ref[1]) { snprintf(w->err.text, sizeof w->err.text, "the ctx created by the main thread gave checksum %016llx, the serial run %016llx",
+                                               (unsigned long long)sum, (unsigned long long)w->ref[1]); w->status = 1; }
+    }
     for (int r = 0; r < w->rounds && !w->status; ++r)
         for (int k = 0; k < N_JOBS && !w->status; ++k) {
             const int job = (k + 2 * w->index + r) % N_JOBS; /* neighbours run different jobs at any moment */
             uint64_t sum = 0;
-            if (run_job(job, 100u + 10u * (uint32_t)job, &sum, &w->err) != 0) w->status = 1;
+            if (run_job(job, 100u + 10u * (uint32_t)job, &sum, &w->err, NULL) != 0) w->status = 1;
             else if (sum != w->ref[job]) {
                 snprintf(w->err.text, sizeof w->err.text, "job %d, round %d: checksum %016llx, the serial run gave %016llx", job, r,
                          (unsigned long long)sum, (unsigned long long)w->ref[job]);
@@ -248,10 +261,10 @@ int main(int argc, char **argv)
     uint64_t ref[N_JOBS];
     err_t err;
     for (int j = 0; j < N_JOBS; ++j) /* the serial run */
-        if (run_job(j, 100u + 10u * (uint32_t)j, &ref[j], &err) != 0) { fprintf(stderr, "thread_stress: serial job %d: %s\n", j, err.text); return 1; }
+        if (run_job(j, 100u + 10u * (uint32_t)j, &ref[j], &err, NULL) != 0) { fprintf(stderr, "thread_stress: serial job %d: %s\n", j, err.text); return 1; }
     { /* a checksum that could not see a wrong pipeline would prove nothing: the jobs that must differ do */
         uint64_t again = 0;
-        if (run_job(1, 110u, &again, &err) != 0 || again != ref[1]) { fprintf(stderr, "thread_stress: job 1 is not reproducible when run alone\n"); return 1; }
+        if (run_job(1, 110u, &again, &err, NULL) != 0 || again != ref[1]) { fprintf(stderr, "thread_stress: job 1 is not reproducible when run alone\n"); return 1; }
         if (ref[0] == ref[1] || ref[1] == ref[2] || ref[6] == ref[1] || ref[7] == ref[1]) { fprintf(stderr, "thread_stress: jobs that must differ share a checksum\n"); return 1; }
     }
     const uint64_t host_ref = host_only();
@@ -262,12 +275,15 @@ int main(int argc, char **argv)
     pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof *th);
     for (int i = 0; i < threads; ++i) {
         w[i].index = i; w[i].rounds = rounds; w[i].ref = ref; w[i].host_ref = host_ref; w[i].gate = &gate;
+        const ovrfsr_config c1 = job_config(1);
+        if (ovrfsr_create(0, &c1, &w[i].handed) != OVRFSR_OK) { fprintf(stderr, "thread_stress: ovrfsr_create for thread %d\n", i); return 1; }
         pthread_create(&th[i], NULL, worker, &w[i]);
     }
     int bad = 0;
     for (int i = 0; i < threads; ++i) {
         pthread_join(th[i], NULL);
         if (w[i].status) { fprintf(stderr, "thread_stress: thread %d: %s\n", i, w[i].err.text); bad = 1; }
+        ovrfsr_destroy(w[i].handed); /* made here, driven there, destroyed here */
     }
     pthread_barrier_destroy(&gate);
     free(w); free(th);
