@@ -17,10 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST_TESTS = ["tests/test_capi.py", "tests/test_constants.py", "tests/test_config_file.py"]
 
 
+SAN = "-fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined"   # tools/build_asan.sh
+
+
 def _build():
-    r = subprocess.run([os.path.join(ROOT, "tools", "build_asan.sh")], capture_output=True, text=True, timeout=900)
-    if r.returncode != 0:
-        pytest.skip("sanitizer build unavailable here: " + (r.stderr or r.stdout)[-300:])
+    # (a fresh stamp = built from these sources: the object directories do not travel to the GPU box, so `make` there would start from nothing)
+    products = [os.path.join(ROOT, "ab", f) for f in ("asan.so", "asan_gcc.so", "headless_asan", "bench_node_asan")]
+    fresh = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variant_fresh.py"), "asan", SAN]).returncode == 0
+    if not (fresh and all(os.path.exists(f) for f in products)):
+        r = subprocess.run([os.path.join(ROOT, "tools", "build_asan.sh")], capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            pytest.skip("sanitizer build unavailable here: " + (r.stderr or r.stdout)[-300:])
     rt = subprocess.run([os.path.join(ROOT, "tools", "build_asan.sh"), "--runtime"], capture_output=True, text=True).stdout.strip()
     assert os.path.exists(rt), rt
     return rt
