@@ -228,7 +228,10 @@ OVRFSR_API int ovrfsr_output_size(const ovrfsr_config *cfg, uint32_t in_width, u
  *           and joined back into `stream` with events: consecutive calls on one ctx must be ordered by the
  *           caller -- same stream, or synchronised streams -- exactly like draws on one D3D11 immediate context.
  *           After the first call for a given input size a call allocates nothing and can be captured into a
- *           HIP graph.
+ *           HIP graph.  A call that WOULD have to build something while `stream` is being captured (the first call for an
+ *           input size, a larger batch than any before, the first use of the ctx-owned output) is refused with
+ *           OVRFSR_ERR_INVALID_ARGUMENT before it touches anything -- the capture stays valid, the ctx stays enabled: make
+ *           the same call once outside the capture.  A captured call records no debug-mode timestamps.
  * (Re)builds constants on first use and whenever the input size changes (PostProcessor.cpp:136-153). */
 OVRFSR_API int ovrfsr_apply(ovrfsr_ctx *ctx, int eye, const ovrfsr_image *in, const ovrfsr_bounds *bounds,
                             ovrfsr_image *out, void *stream);

@@ -214,6 +214,7 @@ static hipError_t fused_go(int mid_fmt, bool strict, const FusedArgs &a, dim3 gr
 
 hipError_t launch_fused(int prec, int in_fmt, int mid_fmt, int out_fmt, const FusedArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
+    launch_fresh();
     FusedArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
@@ -273,6 +274,7 @@ template <int I, int O> static hipError_t outside_staged_go24(int mid_fmt, const
 
 hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt, const OutsideArgs &a_in, uint32_t nTiles, uint32_t batch, hipStream_t s)
 {
+    launch_fresh();
     OutsideArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || !a.tileRec || !a.bilX || !a.bilY || nTiles == 0 || !outside_staged_ok(a.v, in_fmt)) return hipErrorInvalidValue;
@@ -292,6 +294,7 @@ hipError_t launch_outside_staged(int tileH, int in_fmt, int mid_fmt, int out_fmt
 // nTiles blocks, each resolving tile a.tileList[block]: tiles entirely outside the radius (product build only).
 hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuArgs &a_in, uint32_t nTiles, uint32_t batch, hipStream_t s)
 {
+    launch_fresh();
     EasuArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || nTiles == 0) return hipErrorInvalidValue;
@@ -325,6 +328,7 @@ __global__ __launch_bounds__(256) void bgra_to_rgba_kernel(const uint8_t *__rest
 hipError_t launch_bgra_to_rgba(const uint8_t *src, uint32_t srcPitch, uint64_t srcStride, uint8_t *dst, uint32_t w, uint32_t h,
                                uint32_t batch, hipStream_t s)
 {
+    launch_fresh();
     hipLaunchKernelGGL(bgra_to_rgba_kernel, dim3((w + 255) / 256, h, batch), dim3(256), 0, s, src, srcPitch, srcStride, dst, w, h);
     return hipGetLastError();
 }
@@ -408,6 +412,7 @@ hipError_t tie_audit_read(unsigned long long out[6], bool reset)
 
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
+    launch_fresh();
     EasuArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
@@ -419,6 +424,7 @@ hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a_in, 
 
 hipError_t launch_rcas(int prec, int in_fmt, int out_fmt, const RcasArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nTiles)
 {
+    launch_fresh();
     RcasArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     a.dppTilesXMagic = div_magic((uint32_t)(a.v.outW + kRcasDppTileW - 1) / kRcasDppTileW);

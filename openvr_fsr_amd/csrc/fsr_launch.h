@@ -6,6 +6,12 @@
 
 namespace ovrfsr {
 size_t easu_lds_bytes(int prec, int in_fmt, int cellsW, int cellsH);
+// HIP keeps a host thread's last error until somebody reads it, and a kernel launch reports its failure only there.  Every launch_* below
+// reads (= clears) it BEFORE launching, so that what it returns afterwards is its own launch's -- not an error the HOST's code left behind:
+// a failed hipMalloc of the caller's, handled through its return value, used to fail the next frame as "EASU launch: out of memory"
+// (tests/debug/stale_error.c, round 6).
+inline void launch_fresh() { (void)hipGetLastError(); }
+
 hipError_t launch_easu(int prec, int in_fmt, int out_fmt, const EasuArgs &a, uint32_t batch, hipStream_t s, uint32_t nTiles = 0);
 hipError_t launch_easu_outside(int in_fmt, int mid_fmt, int out_fmt, const EasuArgs &a, uint32_t nTiles, uint32_t batch, hipStream_t s);
 size_t fused_lds_bytes(int prec, int in_fmt, int mid_fmt, int cellsW, int cellsH);

@@ -77,6 +77,7 @@ static hipError_t nis_outside_go(const NisArgs &a, dim3 grid, hipStream_t s)
 
 hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a_in, uint32_t nGroups, uint32_t batch, hipStream_t s)
 {
+    launch_fresh();
     NisArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (!a.tileList || nGroups == 0) return hipErrorInvalidValue;
@@ -92,6 +93,7 @@ hipError_t launch_nis_outside(int in_fmt, int out_fmt, const NisArgs &a_in, uint
 
 hipError_t launch_nis_scaler(int prec, int in_fmt, int out_fmt, const NisArgs &a_in, uint32_t batch, hipStream_t s, uint32_t nGroups)
 {
+    launch_fresh();
     NisArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;
@@ -122,6 +124,7 @@ hipError_t bounds_read_nis(unsigned long long *, bool) { return hipErrorNotSuppo
 
 hipError_t launch_nis_sharpen(int prec, int in_fmt, int out_fmt, const NisArgs &a_in, uint32_t batch, hipStream_t s)
 {
+    launch_fresh();
     NisArgs a = a_in;
     a.tilesXMagic = div_magic(a.tilesX);
     if (prec != PREC_FP32 && prec != PREC_FP32_STRICT) return hipErrorInvalidValue;

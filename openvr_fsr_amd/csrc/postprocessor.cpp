@@ -50,6 +50,18 @@ static inline hipError_t stream_create(hipStream_t *s, int prioMode, int least, 
 }
 
 // a*b+c with two roundings, identical to the kernels' mad_unfused (separate statements)
+// A stream that is being captured into a HIP graph takes launches and event fork / join only: an allocation or a table upload fails with
+// "operation not permitted when stream is capturing", INVALIDATES the caller's capture and, as a failed rebuild, used to leave the ctx
+// disabled.  A call that would have to (re)build under capture is refused before it touches anything (round 6; header, `stream`).
+// (the legacy stream cannot be captured, and asking about it while another stream captures would itself invalidate that capture)
+static bool stream_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return s != nullptr && hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+static const char *const kCaptureRefusal = "this call has to build device resources (the first call for an input size, a larger batch, a new output image), "
+                                           "which a capturing stream does not permit: make the same call once outside the capture";
+
 static inline float mad2(float a, float b, float c)
 {
     volatile float t = a * b;
@@ -198,6 +210,7 @@ int PostProcessor::CheckImage(const ovrfsr_image *img, const char *name)
 int PostProcessor::EnsureBuffer(void **buf, size_t *have, size_t need)
 {
     if (*have >= need) return OVRFSR_OK;
+    if (capturing_) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, kCaptureRefusal);
     if (*buf) (void)hipFree(*buf);
     *buf = nullptr;
     *have = 0;
@@ -897,7 +910,8 @@ int PostProcessor::ApplyPostProcess(uint32_t n, int firstEye, int alternate, con
     // instead of surfacing as a launch error behind the EASU pass -- found by the round-6 format sweep)
     if (outTen && doUpscale_ && doSharpen_ && IntermediateFormat() != OVRFSR_FORMAT_RGB10A2_UNORM)
         return Fail(OVRFSR_ERR_UNSUPPORTED, "RGB10A2 pipelines keep a 10-bit intermediate (quantize_intermediate = 1)");
-    const bool timing = cfg_.debug_mode && queries_[kQueryCount - 1].end; // (the ring is complete: slots are created in order)
+    // (the ring is complete: slots are created in order; a call that is being captured into a graph is not timed: its events could never be read back)
+    const bool timing = cfg_.debug_mode && !capturing_ && queries_[kQueryCount - 1].end;
     if (timing) (void)hipEventRecord(queries_[currentQuery_].start, stream);
     int rc = OVRFSR_OK;
     if (useSorted_) {
@@ -956,6 +970,9 @@ int PostProcessor::Apply(int eye, const ovrfsr_image *in, const ovrfsr_bounds *b
     DeviceGuard guard(device_);
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
 
+    capturing_ = stream_capturing(stream);
+    if (capturing_ && (!initialized_ || in->width != inputWidth_ || in->height != inputHeight_ || in->format != inputFormat_))
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, kCaptureRefusal); // (nothing touched: the capture stays valid, the ctx stays enabled)
     if (initialized_ && (in->width != inputWidth_ || in->height != inputHeight_ || in->format != inputFormat_)) {
         bool keep = false;
         if (havePending_) { // the recorded eye belongs to the old resources
@@ -1091,6 +1108,9 @@ int PostProcessor::ApplyBatch(uint32_t n, int firstEye, int alternate, const ovr
     if (RangesOverlap(*in0, inStride, *out0, outStride, n)) return Fail(OVRFSR_ERR_INVALID_ARGUMENT, "input and output batches overlap");
     DeviceGuard guard(device_);
     if (guard.err != hipSuccess) return Fail(OVRFSR_ERR_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+    capturing_ = stream_capturing(stream);
+    if (capturing_ && (!initialized_ || in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || textureContainsOnlyOneEye_ == sharedTextures))
+        return Fail(OVRFSR_ERR_INVALID_ARGUMENT, kCaptureRefusal);
     if (havePending_) { rc = FlushPending(stream); if (rc != OVRFSR_OK) return rc; } // cfg.pair_submit: a recorded LEFT goes first
     // shared side-by-side textures: both mask centres per image, processed once each (PostProcessor.cpp:146,155-158,298-301)
     if (initialized_ && (in0->width != inputWidth_ || in0->height != inputHeight_ || in0->format != inputFormat_ || textureContainsOnlyOneEye_ == sharedTextures))

@@ -99,6 +99,7 @@ private:
     bool pairDefer_ = true;          // false after the same eye came twice in a row, until the other eye is seen again
     int lastEye_ = -1;
     bool lastApplyRecorded_ = false; // the last Apply only recorded its submission (ovrfsr_pair_pending)
+    bool capturing_ = false;         // the stream of the call in progress is being captured into a HIP graph: launches only, no (re)build
     ovrfsr_image pendingIn_{}, pendingOut_{};
     void *retired_ = nullptr; // a ctx-owned output image a flushed pair_submit eye was handed in, kept across the rebuild of a size change
     void ResetKeeping(bool keepRetired);

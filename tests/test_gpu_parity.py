@@ -656,6 +656,56 @@ def test_hip_graph_capture_and_replay(gpu, dtype, radius, nis):
     pp.close()
 
 
+@pytest.mark.parametrize("radius,debug", [(2.0, 0), (0.5, 0), (0.5, 1)])
+def test_a_call_that_must_build_is_refused_under_capture(gpu, radius, debug):
+    """A capturing stream takes launches only.  A cold ctx (or a larger batch than any before) under capture used to fail inside the rebuild with
+    "operation not permitted when stream is capturing": the caller's capture invalidated, the ctx DISABLED until reset.  Now the call is refused
+    up front (INVALID_ARGUMENT, header `stream`): the capture survives, the ctx stays usable, and the same capture succeeds after one plain call
+    -- also in debug mode, whose timing ring a captured call leaves alone."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 150, 120, 200, 160
+    t = torch.from_numpy(np.stack([synth.structured_u8(iw, ih, 40 + i) for i in range(4)])).cuda()
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.8, radius=radius, debug_mode=debug)
+    out = torch.zeros((4, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    ref = torch.zeros_like(out)
+    side = torch.cuda.Stream()
+
+    def capture(n):
+        g = torch.cuda.CUDAGraph()
+        side.wait_stream(torch.cuda.current_stream())
+        err = None
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):          # (leaving the block ends the capture: it must still be valid)
+                try:
+                    pp.apply_batch(t[:n], out[:n], first_eye=0, alternate_eyes=True)
+                except A.OvrFsrError as e:
+                    err = e
+        torch.cuda.synchronize()
+        return g, err
+
+    g, err = capture(2)                                     # cold ctx
+    assert err is not None and err.status == 1 and "capturing stream" in str(err), err
+    pp.apply_batch(t[:2], ref[:2], first_eye=0, alternate_eyes=True)   # no reset needed: the refusal disabled nothing
+    torch.cuda.synchronize()
+    g, err = capture(2)                                     # warm: captured
+    assert err is None
+    out.zero_(); g.replay(); torch.cuda.synchronize()
+    assert torch.equal(out[:2], ref[:2])
+    g4, err = capture(4)                                    # a larger batch needs a larger intermediate: refused again (two-kernel pipelines)
+    if err is not None:
+        assert err.status == 1   # INVALID_ARGUMENT
+    pp.apply_batch(t, ref, first_eye=0, alternate_eyes=True)
+    torch.cuda.synchronize()
+    g4, err = capture(4)
+    assert err is None
+    out.zero_(); g4.replay(); torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    if debug:
+        assert pp.last_gpu_time_ms() > 0                    # the plain calls were timed, the captured ones left the ring alone
+    pp.close()
+
+
 def test_plain_c_caller(gpu, tmp_path):
     """examples/headless (plain C11, built by __graft_entry__.build()): create, apply both eyes with a ctx-owned output,
     debug-mode GPU time, PPM capture -- the C ABI end to end without Python in the loop."""

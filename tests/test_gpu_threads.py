@@ -30,6 +30,16 @@ def _product_driver():
     return exe
 
 
+def _c_driver(name, extra=()):
+    exe = os.path.join(ROOT, "tests", "debug", name)
+    if not os.path.exists(exe):
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        subprocess.check_call(["gcc", "-std=c11", "-O2", "-D_POSIX_C_SOURCE=200809L", "-D__HIP_PLATFORM_AMD__", *extra, exe + ".c", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(rocm, "include"), "-L" + os.path.join(ROOT, "openvr_fsr_amd"), "-lopenvr_fsr_amd", "-L" + os.path.join(rocm, "lib"),
+                               "-lamdhip64", "-lm", "-Wl,-rpath,$ORIGIN/../../openvr_fsr_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", exe])
+    return exe
+
+
 def _tsan_driver():
     exe = os.path.join(ROOT, "ab", "thread_stress_tsan")
     fresh = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "variant_fresh.py"), "tsan", SAN]).returncode == 0
@@ -65,6 +75,15 @@ def test_thread_sanitizer_build_is_live(gpu):
     out = r.stdout + r.stderr
     assert "WARNING: ThreadSanitizer: data race" in out and "ovrfsr::PostProcessor" in out, out[-3000:]
     assert r.returncode == 66, r.returncode
+
+
+@pytest.mark.gpu
+def test_a_pending_hip_error_of_the_callers_does_not_fail_the_next_apply(gpu):
+    """HIP keeps a thread's last error until it is read, and a launch reports failure only there: the host's own failed hipMalloc (handled
+    through its return value) used to fail the next frame as "EASU launch: out of memory".  Every launch_* now clears the state first
+    (csrc/fsr_launch.h launch_fresh); tests/debug/stale_error.c: apply, provoke the error, apply and reset + rebuild -- same pixels."""
+    r = subprocess.run([_c_driver("stale_error")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "neither failed nor changed" in r.stdout, (r.stdout + r.stderr)[-2000:]
 
 
 def test_thread_stress_driver_compiles_warning_free(tmp_path):
