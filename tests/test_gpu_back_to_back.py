@@ -225,6 +225,57 @@ def test_back_to_back_with_changing_batch_sizes(cfg):
         pp.close()
 
 
+LIFE_CASES = [
+    ("sorted two-pass RGBA8", dict(radius=0.5, sharpness=0.9), np.uint8),
+    ("fused + outside RGBA16F (forked)", dict(radius=0.5, sharpness=0.9), np.float16),
+    ("NVScaler masked", dict(radius=0.45, sharpness=0.8, use_nis=1), np.uint8),
+    ("unmasked two-pass, debug mode", dict(radius=2.0, sharpness=0.9, debug_mode=1), np.uint8),
+]
+
+
+@pytest.mark.parametrize("name,cfg,dt", LIFE_CASES, ids=[c[0] for c in LIFE_CASES])
+def test_reset_set_config_and_destroy_with_work_in_flight(name, cfg, dt):
+    """Reset(), a hotkey's set_config and the destructor release tile lists, tap tables, the intermediate, events and the auxiliary stream
+    (PostProcessor.cpp:166-194, 659-709) -- here with the previous call's kernels possibly still running, as a render thread does it: no host
+    synchronisation anywhere between the calls.  Every output equals the one the same configuration gave with full synchronisation; the
+    last ctx is destroyed with work in flight and its outputs are read afterwards."""
+    import copy
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh, n = 640, 540, 853, 720, 4
+    tdt = {np.uint8: torch.uint8, np.float16: torch.float16}[dt]
+    src = _batch(dt, 11, n, iw, ih)
+    alt = dict(cfg, sharpness=0.3, radius=0.7 if cfg["radius"] < 2 else 2.0)      # what a hotkey changes
+    ref = {}
+    for key, c in (("a", cfg), ("b", alt)):
+        pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **c)
+        ref[key] = torch.zeros((n, oh, ow, 4), dtype=tdt, device="cuda")
+        pp.apply_batch(src, ref[key])
+        torch.cuda.synchronize()
+        pp.close()
+    assert not torch.equal(ref["a"], ref["b"])
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, precision=FP32, **cfg)
+    cfg_a, cfg_b = copy.copy(pp.cfg), copy.copy(pp.cfg)
+    cfg_b.sharpness, cfg_b.radius = alt["sharpness"], alt["radius"]
+    script = ["a", "reset", "a", "b", "b", "reset", "b", "a", "a", "reset", "a", "b"]
+    outs, want, cur = [], [], "a"
+    torch.cuda.synchronize()
+    for step in script:
+        if step == "reset":
+            pp.reset()
+            continue
+        if step != cur:
+            pp.set_config(cfg_a if step == "a" else cfg_b)
+            cur = step
+        o = torch.zeros((n, oh, ow, 4), dtype=tdt, device="cuda")
+        pp.apply_batch(src, o)
+        outs.append(o); want.append(step)
+    pp.close()                                    # destructor with the last calls in flight
+    torch.cuda.current_stream().synchronize()
+    for k, (o, w) in enumerate(zip(outs, want)):
+        assert torch.equal(o, ref[w]), "call %d (configuration %s) differs from the synchronised run" % (k, w)
+
+
 # ------------------------------------------------------------------------------------------------
 # round 5: cfg.pair_submit -- apply(LEFT) is recorded, apply(RIGHT) launches both eyes as one batch of two
 # ------------------------------------------------------------------------------------------------
