@@ -49,7 +49,6 @@ static inline hipError_t stream_create(hipStream_t *s, int prioMode, int least, 
     return prioMode == 0 ? hipStreamCreateWithFlags(s, hipStreamNonBlocking) : hipStreamCreateWithPriority(s, hipStreamNonBlocking, prioMode == 1 ? least : greatest);
 }
 
-// a*b+c with two roundings, identical to the kernels' mad_unfused (separate statements)
 // A stream that is being captured into a HIP graph takes launches and event fork / join only: an allocation or a table upload fails with
 // "operation not permitted when stream is capturing", INVALIDATES the caller's capture and, as a failed rebuild, used to leave the ctx
 // disabled.  A call that would have to (re)build under capture is refused before it touches anything (round 6; header, `stream`).
@@ -62,6 +61,7 @@ static bool stream_capturing(hipStream_t s)
 static const char *const kCaptureRefusal = "this call has to build device resources (the first call for an input size, a larger batch, a new output image), "
                                            "which a capturing stream does not permit: make the same call once outside the capture";
 
+// a*b+c with two roundings, identical to the kernels' mad_unfused (separate statements)
 static inline float mad2(float a, float b, float c)
 {
     volatile float t = a * b;

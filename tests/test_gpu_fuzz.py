@@ -201,6 +201,66 @@ def test_extreme_shapes(gpu, iw, ih, ow, oh):
         assert np.abs(gotp.astype(np.int16) - want.astype(np.int16)).max() <= 1, (radius,)
 
 
+MAX_AREA = [
+    ("EASU only RGBA8 -> RGBA32F, strict (4 GiB output: byte offsets up to 2^32 - 16)", dict(stage_mask=1, precision=STRICT), "u8", "f32"),
+    ("EASU + RCAS RGBA16F, product (2 GiB output and intermediate)", dict(sharpness=0.7), "f16", "f16"),
+    ("fused RGBA16F, product", dict(sharpness=0.7, fused=1), "f16", "f16"),
+    ("NVScaler RGBA8 -> RGBA8 (1 GiB output)", dict(use_nis=1, sharpness=0.5), "u8", "u8"),
+]
+
+
+@pytest.mark.parametrize("name,cfg,inf,outf", MAX_AREA, ids=[c[0].split(" (")[0] for c in MAX_AREA])
+def test_largest_image_addresses_every_band_like_a_small_one(gpu, name, cfg, inf, outf):
+    """The largest image the ABI accepts at FULL area: 12288 x 12288 -> 16384 x 16384 (the strips of test_extreme_shapes reach the largest
+    coordinate, not the largest byte offset).  Too large for the oracle; the property instead: at a scale of exactly 3/4 the band of output rows
+    [4k, 4k + 400) depends on input rows [3k, 3k + 300) only (plus the filter's reach), so away from the band's own borders it must equal, bit for
+    bit, what the library writes for that band of the input submitted as an image of its own -- an image small enough that every path it takes is
+    pinned to the oracle elsewhere.  A 32-bit offset that wraps, a tile index that overflows or a row that lands in another tile shows up as a
+    difference; bands at the top, in the middle, across the 2 GiB line and at the very end of the output."""
+    import torch
+    import openvr_fsr_amd as A
+    IW = IH = 12288
+    OW = OH = 16384
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    tin = {"u8": torch.uint8, "f16": torch.float16}[inf]
+    tout = {"u8": torch.uint8, "f16": torch.float16, "f32": torch.float32}[outf]
+    src = torch.empty((IH, IW, 4), dtype=tin, device="cuda")
+    for r0 in range(0, IH, 1024):                      # smooth + noisy content, generated in slabs (no 2.4 GB temporaries)
+        yy = torch.arange(r0, r0 + 1024, device="cuda", dtype=torch.float32)[:, None, None]
+        xx = torch.arange(IW, device="cuda", dtype=torch.float32)[None, :, None]
+        ch = torch.arange(4, device="cuda", dtype=torch.float32)[None, None, :]
+        v = 127.5 + 90.0 * torch.sin(xx * 0.013 + ch) * torch.cos(yy * 0.011 - ch) + 30.0 * (torch.rand((1024, IW, 4), generator=g, device="cuda") - 0.5)
+        v = v.clamp_(0, 255)
+        src[r0:r0 + 1024] = v.to(torch.uint8) if inf == "u8" else (v / 255.0).to(torch.float16)
+        del v
+    out = torch.zeros((OH, OW, 4), dtype=tout, device="cuda")
+    pp = A.PostProcessor(fsr_enabled=1, out_width=OW, out_height=OH, radius=2.0, **cfg)
+    # (the radius is in units of outH / 2: 2.0 covers a square image, a 16384 x 400 band needs 50 to stay unmasked out to its corners)
+    small = A.PostProcessor(fsr_enabled=1, out_width=OW, out_height=400, radius=50.0, **cfg)
+    try:
+        pp.apply_batch(src[None], out[None], first_eye=0)
+        torch.cuda.synchronize()
+        band = torch.zeros((400, OW, 4), dtype=tout, device="cuda")
+        # Rows of the band compared: not the band's first and last TILE row (32 rows; 16 at the short last one).  Those see the band's own
+        # clamped borders (NVScaler's 6-tap filter + edge map, RCAS behind EASU) -- and in the product build the tiles that touch an image
+        # border run the bounds-checking instantiation of a kernel, whose contracted multiply-adds round a few pixels per million differently
+        # from the interior instantiation (one half-ulp, inside the contract; found by this test: 29 of 6 M pixels of the half pipeline).
+        edge = 32
+        for k in (0, 1365, 2047, 2048, 2730, 3996):    # output rows 4k ..: top, 1/3, the 2 GiB line of a 4 GiB image, 2/3, the last band
+            small.apply_batch(src[3 * k:3 * k + 300][None].contiguous(), band[None], first_eye=0)
+            torch.cuda.synchronize()
+            # (the image's own top / bottom borders ARE the band's; the last band starts half a tile row into the image's tiling: its rows
+            # 368..383 are border-tile rows of the image and interior rows of the band)
+            spans = [(0, 384)] if k == 0 else [(edge, 368), (384, 400)] if 4 * k + 400 == OH else [(edge, 384)]
+            for lo, hi in spans:
+                a, b = out[4 * k + lo:4 * k + hi], band[lo:hi]
+                if not torch.equal(a.view(torch.uint8), b.view(torch.uint8)):
+                    bad = (a != b).any(dim=2).nonzero()
+                    raise AssertionError("%s: band at output row %d differs at %d pixels, first (row, column) %s" % (name, 4 * k, bad.shape[0], (bad[0] + torch.tensor([lo, 0], device=bad.device)).tolist()))
+    finally:
+        pp.close(); small.close()
+
+
 @pytest.mark.parametrize("iw,ih,ow,oh", [(12288, 6, 16384, 8), (6, 12288, 8, 16384), (3, 2, 4, 3)])
 def test_extreme_shapes_nis(gpu, iw, ih, ow, oh):
     import openvr_fsr_amd as A
