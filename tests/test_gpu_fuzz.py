@@ -201,6 +201,34 @@ def test_extreme_shapes(gpu, iw, ih, ow, oh):
         assert np.abs(gotp.astype(np.int16) - want.astype(np.int16)).max() <= 1, (radius,)
 
 
+@pytest.mark.parametrize("cfg", [dict(radius=2.0, sharpness=0.8), dict(radius=0.6, sharpness=0.8), dict(radius=0.6, use_nis=1, sharpness=0.5), dict(radius=0.7, fused=1)],
+                         ids=["two-pass", "masked sorted", "NVScaler masked", "fused masked"])
+def test_largest_batch_in_one_launch(gpu, cfg):
+    """65 535 images in one call (the grid's z extent; one more is refused): images 0, 1, 32 767, 65 533 and 65 534 equal what the same
+    ctx writes for them one at a time -- the image index, its eye parity and `base + i * stride` at their extremes."""
+    import torch
+    import openvr_fsr_amd as A
+    n, iw, ih, ow, oh = 65535, 36, 27, 48, 36
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    src = torch.randint(0, 256, (n, ih, iw, 4), dtype=torch.uint8, device="cuda", generator=g)
+    out = torch.zeros((n, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, proj_centre=(0.4, 0.5, 0.6, 0.5), **cfg)
+    try:
+        pp.apply_batch(src, out, first_eye=0, alternate_eyes=True)
+        torch.cuda.synchronize()
+        one = torch.zeros((1, oh, ow, 4), dtype=torch.uint8, device="cuda")
+        for i in (0, 1, 32767, 65533, 65534):
+            pp.apply_batch(src[i:i + 1], one, first_eye=i & 1)
+            torch.cuda.synchronize()
+            assert torch.equal(out[i], one[0]), "image %d of the batch differs from the same image on its own" % i
+        big = torch.zeros((n + 1, ih, iw, 4), dtype=torch.uint8, device="cuda")
+        with pytest.raises(A.OvrFsrError) as e:
+            pp.apply_batch(big, torch.zeros((n + 1, oh, ow, 4), dtype=torch.uint8, device="cuda"))
+        assert e.value.status == 1 and "65535" in str(e.value)
+    finally:
+        pp.close()
+
+
 MAX_AREA = [
     ("EASU only RGBA8 -> RGBA32F, strict (4 GiB output: byte offsets up to 2^32 - 16)", dict(stage_mask=1, precision=STRICT), "u8", "f32"),
     ("EASU + RCAS RGBA16F, product (2 GiB output and intermediate)", dict(sharpness=0.7), "f16", "f16"),
