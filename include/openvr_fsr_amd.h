@@ -91,6 +91,13 @@ typedef enum ovrfsr_format {
  * hardware keeps MORE sub-texel bits (10, 12, exact float weights), pixels outside the radius move by <= 1 LSB -- none at all at BASELINE's
  * C2 / C3 shape, whose scale is exactly 3/4 (every coordinate a multiple of 1/4), 1.9 % of the bytes at x1.3 (C4 shape) on structured and
  * natural content, 10.8 % on uniform noise; a TRUNCATING snap would move 0.6 % / 3.9 % of them by <= 2 LSB.
+ * TEXEL VALUES the statements above cover (tests/test_gpu_formats.py::test_texel_value_domain): every finite value whose fp32 products do
+ * not overflow -- the whole RGBA16F range, negative values, denormals, RGBA32F magnitudes up to 1e18.  One thing IEEE 754 leaves open shows
+ * through: min / max of a +0 and a -0.  An image holding zeros of BOTH signs can make a result that is a zero carry the other sign than the
+ * oracle's (x86 and gfx950 choose differently); colour images (values >= +0) never meet it.  NaN / +-Inf texels, and magnitudes whose products
+ * overflow (1e30), are outside the parity contract and inside the memory-safety one: what the pixels whose taps reach such a texel hold is
+ * implementation-defined (EASU / RCAS: the same pixels are NaN in every build and in the oracle), every other pixel is unaffected, nothing is
+ * read or written out of place (checked build, profiles/r06_bounds.txt).
  * There is no packed-half arithmetic mode (value 1 was reserved for one in ABI 1 and is rejected with
  * OVRFSR_ERR_INVALID_ARGUMENT by ovrfsr_create / ovrfsr_set_config): on gfx950 v_pk_*_f16 issues at the rate of
  * v_pk_*_f32 (profiles/r02_valu_issue_rates.txt), the fp32 kernels already process two taps per packed instruction, and

@@ -286,3 +286,72 @@ def test_capture_dds(gpu, tmp_path, dt):
     px = np.frombuffer(data[148:], dt).reshape(oh, ow, 4)
     assert np.array_equal(px.view(np.uint8), view.contiguous().cpu().numpy().view(np.uint8))
     assert A.library().ovrfsr_save_dds(None, path.encode(), None) == 1
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: the DOMAIN of texel values the parity statements cover (header, "Texel values")
+# ------------------------------------------------------------------------------------------------
+def _wild(kind, w, h, rng):
+    """float32 RGBA texels far from a colour image"""
+    if kind == "half extremes, non-negative":
+        img = rng.choice(np.array([65504.0, 6e-8, 0.0, 1.0, 1e-3, 3e4, 2.5, 0.5], np.float32), size=(h, w, 4))
+    elif kind == "half extremes, negative values, no zeros":
+        img = rng.choice(np.array([65504.0, -65504.0, 6e-8, -6e-8, 1.0, 1e-3, 3e4, -2.5], np.float32), size=(h, w, 4))
+    elif kind == "zeros of both signs":
+        img = rng.choice(np.array([65504.0, 0.0, -0.0, 1.0, 1e-3, 3e4, 2.5], np.float32), size=(h, w, 4))
+    else:
+        img = rng.standard_normal((h, w, 4)).astype(np.float32) * np.float32(10.0 ** rng.uniform(-3, 3))
+        sel = rng.random((h, w, 4))
+        img[sel < 0.05] = 0.0
+        img[(sel >= 0.05) & (sel < 0.08)] = np.float32(1e-41)                      # fp32 denormals
+        if kind == "up to 1e18, denormals, zeros":
+            img *= np.float32(1e18 / float(np.abs(img).max()))
+        if kind == "NaN / Inf / 1e30":
+            img[(sel >= 0.08) & (sel < 0.10)] = np.float32(1e30)
+            img[(sel >= 0.10) & (sel < 0.12)] = np.float32(-1e30)
+            img[(sel >= 0.12) & (sel < 0.13)] = np.nan
+            img[(sel >= 0.13) & (sel < 0.14)] = np.inf
+            img[(sel >= 0.14) & (sel < 0.15)] = -np.inf
+    img = np.ascontiguousarray(img, np.float32)
+    img[..., 3] = 1.0
+    return img
+
+
+@pytest.mark.parametrize("kind", ["half extremes, non-negative", "half extremes, negative values, no zeros", "up to 1e18, denormals, zeros",
+                                  "zeros of both signs", "NaN / Inf / 1e30"])
+def test_texel_value_domain(gpu, kind):
+    """What the bit-identity of the strict build covers, probed with RGBA32F texels no colour image holds (header, "Texel values"):
+      * every finite value whose fp32 products do not overflow -- the extremes of the half range, negative values, fp32 denormals, 1e18: bit for bit;
+      * zeros of BOTH signs: IEEE 754 leaves min / max of a +0 and a -0 open and x86 (the oracle) and gfx950 choose differently, so a result that is
+        a zero may carry the other sign -- and nothing else differs;
+      * NaN / Inf texels and magnitudes whose products overflow (1e30): outside the contract -- but the same pixels are NaN in every build and in the
+        oracle, the finite ones stay finite, and nothing hangs (memory safety: tools/debug/bounds_campaign.py runs these families)."""
+    import torch
+    import openvr_fsr_amd as A
+    iw, ih, ow, oh = 150, 110, 200, 147
+    centre, rad = O.mask_constants(ow, oh, 2.0)
+    con = O.easu_con(iw, ih, ow, oh)
+    for seed in range(4):
+        img = _wild(kind, iw, ih, np.random.default_rng(50 + seed))
+        t = torch.from_numpy(img).cuda()
+        we = O.easu(img, ow, oh, con, centre, rad)
+        wr = O.rcas(we, O.rcas_con(0.8, 0), centre, rad)
+        for stage, want, kw in (("easu", we, dict(stage_mask=1)), ("easu+rcas", wr, dict(quantize_intermediate=0, fused=0))):
+            for prec in (STRICT, FP32):
+                pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, sharpness=0.8, radius=2.0, precision=prec, **kw)
+                out = torch.zeros((oh, ow, 4), dtype=torch.float32, device="cuda")
+                pp.apply_batch(t[None], out[None])
+                torch.cuda.synchronize()
+                pp.close()
+                got, w3 = out.cpu().numpy()[..., :3], want[..., :3]
+                if kind == "NaN / Inf / 1e30":
+                    assert np.array_equal(np.isnan(got), np.isnan(w3)), (kind, stage, prec, seed)
+                    continue
+                assert np.isfinite(got).all()
+                if prec != STRICT:
+                    continue        # (the product build's tolerances are stated for colour content: tests/test_gpu_parity*.py)
+                same = got.view(np.uint32) == w3.view(np.uint32)
+                if kind == "zeros of both signs":
+                    assert (same | ((got == 0) & (w3 == 0))).all(), (kind, stage, seed, int((~same).sum()))
+                else:
+                    assert same.all(), (kind, stage, seed, int((~same).sum()))

@@ -113,6 +113,15 @@ def to_dev(img, fmt):
     if fmt == "hdr16":
         x = (t.float() * (6.0 / 255.0)).to(torch.float16); x[..., 3] = 1.0
         return x, None
+    if fmt in ("wild32", "wild16"):   # texels no colour image holds: NaN, +-Inf, 1e30 / 65504, denormals, negative values, zeros of both signs
+        rng = np.random.default_rng(int(img.sum()) & 0xffff)
+        big = 1e30 if fmt == "wild32" else 65504.0
+        x = rng.standard_normal(img.shape).astype(np.float32) * np.float32(10.0 ** rng.uniform(-3, 3))
+        sel = rng.random(img.shape)
+        for lo, v in ((0.00, 0.0), (0.04, -0.0), (0.06, 1e-41 if fmt == "wild32" else 6e-8), (0.09, big), (0.11, -big), (0.13, np.nan), (0.14, np.inf), (0.15, -np.inf)):
+            x[(sel >= lo) & (sel < lo + 0.02)] = np.float32(v)
+        x = torch.from_numpy(x).to(DEV)
+        return (x if fmt == "wild32" else x.to(torch.float16)), None
     if fmt == "rgb10":
         v = (t[..., :3].to(torch.int64) * 1023 + 127) // 255
         return ((v[..., 0] | (v[..., 1] << 10) | (v[..., 2] << 20) | (3 << 30)) & 0xffffffff).to(torch.int64).to(torch.int32), None
@@ -268,7 +277,8 @@ def formats():
     iw, ih, ow, oh = 150, 110, 200, 147
     img8 = synth.structured_u8(iw, ih, 5)
     pairs = [("u8", "u8"), ("u8", "f16"), ("u8", "f32"), ("f16", "u8"), ("f16", "f16"), ("f16", "f32"), ("f32", "u8"), ("f32", "f16"), ("f32", "f32"),
-             ("hdr16", "f16"), ("rgb10", "rgb10"), ("rgb10", "f32"), ("bgra8", "u8")]
+             ("hdr16", "f16"), ("rgb10", "rgb10"), ("rgb10", "f32"), ("bgra8", "u8"),
+             ("wild32", "f32"), ("wild32", "u8"), ("wild16", "f16"), ("wild16", "u8")]   # (non-finite / extreme texels: outside the parity contract, inside the memory-safety one)
     for fi, fo in pairs:
         for radius in (2.0, 0.5):
             for prec in (FP32, STRICT):
