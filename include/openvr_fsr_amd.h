@@ -136,7 +136,8 @@ typedef struct ovrfsr_bounds { float uMin, vMin, uMax, vMax; } ovrfsr_bounds;
  *     and negative values give 0, values >= 2^32 give 0xffffffff (the saturating float->uint of the shader model that reads the
  *     cbuffer); radius^2 keeps the reference's uint32 wrap-around (radius * outH / 2 >= 65536: defined, if useless, there too);
  *   - ovrfsr_config_from_json clamps a negative radius to 0 exactly as the reference clamps a negative sharpness, and treats a
- *     number that overflows float as "Could not read config file" (defaults, OVRFSR_ERR_INVALID_ARGUMENT). */
+ *     number that overflows float as "Could not read config file" (defaults, OVRFSR_ERR_INVALID_ARGUMENT); numbers are read in the "C"
+ *     locale whatever locale the host process has set (a comma-decimal LC_NUMERIC would make atof("0.77") return 0). */
 typedef struct ovrfsr_config {
     uint32_t struct_size;    /* = sizeof(ovrfsr_config); ABI guard                               */
     int32_t fsr_enabled;     /* Config::fsrEnabled: 0 -> apply() is a pass-through (output = input

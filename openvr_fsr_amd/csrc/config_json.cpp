@@ -6,7 +6,7 @@
 // Also: a binary PPM dump of a device image, standing in for the F7 DDS capture
 // (PostProcessor.cpp:640-657 via ScreenGrab11) as the "image out" format for visual diffs.
 #include <hip/hip_runtime.h>
-#include <cctype>
+#include <clocale>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +18,17 @@
 
 namespace {
 
+// The text is parsed in the "C" locale whatever the HOST process has set: a game that calls setlocale(LC_ALL, "") on a machine whose decimal
+// separator is a comma makes atof("0.77") return 0 -- renderScale, sharpness and radius all read 0 (round 6; jsoncpp, which the reference
+// uses, is locale-independent too).  Numbers go through strtod_l with an explicit C locale, character classes are ASCII by construction.
+double c_atof(const char *s)
+{
+    static const locale_t c = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+    return c ? strtod_l(s, nullptr, c) : std::strtod(s, nullptr);
+}
+inline bool is_space(char ch) { return ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r' || ch == '\f' || ch == '\v'; }
+inline bool is_alnum(char ch) { return (ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z'); }
+
 // Minimal JSON reader: objects, arrays, strings, numbers, true/false/null, // and /* */ comments.
 // Only the scalar leaves of the top-level "fsr" object are kept, addressed as "key" or "sub.key".
 struct Parser {
@@ -28,7 +39,7 @@ struct Parser {
     void ws()
     {
         for (;;) {
-            while (p < end && std::isspace((unsigned char)*p)) ++p;
+            while (p < end && is_space(*p)) ++p;
             if (p + 1 < end && p[0] == '/' && p[1] == '/') { while (p < end && *p != '\n') ++p; continue; }
             if (p + 1 < end && p[0] == '/' && p[1] == '*') {
                 p += 2;
@@ -77,7 +88,7 @@ struct Parser {
             leaves[path] = str();
         } else {
             const char *s = p;
-            while (p < end && (std::isalnum((unsigned char)*p) || *p == '+' || *p == '-' || *p == '.')) ++p;
+            while (p < end && (is_alnum(*p) || *p == '+' || *p == '-' || *p == '.')) ++p;
             if (p == s) { ok = false; return; }
             leaves[path] = std::string(s, p);
         }
@@ -90,7 +101,7 @@ bool as_bool(const std::map<std::string, std::string> &m, const char *k, bool de
     if (it == m.end()) return def;
     if (it->second == "true") return true;
     if (it->second == "false" || it->second == "null") return false;
-    return std::atof(it->second.c_str()) != 0.0; // jsoncpp asBool(): non-zero numbers are true
+    return c_atof(it->second.c_str()) != 0.0; // jsoncpp asBool(): non-zero numbers are true
 }
 float as_float(const std::map<std::string, std::string> &m, const char *k, double def)
 {
@@ -98,7 +109,7 @@ float as_float(const std::map<std::string, std::string> &m, const char *k, doubl
     if (it == m.end()) return (float)def;
     if (it->second == "true") return 1.0f;
     if (it->second == "false" || it->second == "null") return 0.0f;
-    return (float)std::atof(it->second.c_str()); // asFloat(): double -> float
+    return (float)c_atof(it->second.c_str()); // asFloat(): double -> float
 }
 
 } // namespace
