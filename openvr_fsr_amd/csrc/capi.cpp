@@ -213,25 +213,25 @@ OVRFSR_API int ovrfsr_average_gpu_time_ms(ovrfsr_ctx *ctx, float *ms, uint32_t *
 
 OVRFSR_API void ovrfsr_easu_con(uint32_t con[16], float vw, float vh, float iw, float ih, float ow, float oh)
 {
-    ovrfsr::easu_con(con, vw, vh, iw, ih, ow, oh);
+    if (con) ovrfsr::easu_con(con, vw, vh, iw, ih, ow, oh); // (null outputs: nothing to do -- no entry point dereferences a null it was handed)
 }
 
-OVRFSR_API void ovrfsr_rcas_con(uint32_t con[4], float stops) { ovrfsr::rcas_con(con, stops); }
+OVRFSR_API void ovrfsr_rcas_con(uint32_t con[4], float stops) { if (con) ovrfsr::rcas_con(con, stops); }
 
 OVRFSR_API void ovrfsr_mask_constants(uint32_t centre[4], uint32_t radius[4], uint32_t out_w, uint32_t out_h,
                                       const float proj_centre[4], float cfg_radius, int only_one_eye, int eye)
 {
-    ovrfsr::mask_constants(centre, radius, out_w, out_h, proj_centre, cfg_radius, only_one_eye, eye);
+    if (centre && radius && proj_centre) ovrfsr::mask_constants(centre, radius, out_w, out_h, proj_centre, cfg_radius, only_one_eye, eye);
 }
 
 OVRFSR_API int ovrfsr_nis_scaler_config(void *cfg256, float sharpness, uint32_t in_w, uint32_t in_h, uint32_t out_w, uint32_t out_h)
 {
-    return ovrfsr::nis_scaler_config(cfg256, sharpness, in_w, in_h, out_w, out_h);
+    return cfg256 ? ovrfsr::nis_scaler_config(cfg256, sharpness, in_w, in_h, out_w, out_h) : 0;
 }
 
 OVRFSR_API int ovrfsr_nis_sharpen_config(void *cfg256, float sharpness, uint32_t in_w, uint32_t in_h)
 {
-    return ovrfsr::nis_scaler_config(cfg256, sharpness, in_w, in_h, in_w, in_h);
+    return cfg256 ? ovrfsr::nis_scaler_config(cfg256, sharpness, in_w, in_h, in_w, in_h) : 0;
 }
 
 OVRFSR_API const float *ovrfsr_nis_coef_scale(void) { return ovrfsr::nis_coef_scale(); }

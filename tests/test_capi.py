@@ -183,6 +183,51 @@ def test_null_ctx_is_an_error_not_a_crash():
     L.ovrfsr_destroy(None)
 
 
+def test_no_entry_point_dereferences_a_null_it_was_handed():
+    """every pointer argument of every entry point that can be called without a device, as NULL: a status (or nothing), never a crash --
+    in a subprocess, so that a crash is a test failure and not the end of the test run"""
+    import subprocess
+    import sys
+    code = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import openvr_fsr_amd as A
+L = A.library()
+cfg = A.Config.default(fsr_enabled=1)
+w, h = C.c_uint32(), C.c_uint32()
+L.ovrfsr_config_default(None)
+assert L.ovrfsr_output_size(None, 8, 8, C.byref(w), C.byref(h)) == 1
+assert L.ovrfsr_output_size(C.byref(cfg), 8, 8, None, C.byref(h)) == 1 and L.ovrfsr_output_size(C.byref(cfg), 8, 8, C.byref(w), None) == 1
+assert L.ovrfsr_create(0, None, None) == 1 and L.ovrfsr_create(0, C.byref(cfg), None) == 1
+ctx = C.c_void_p()
+assert L.ovrfsr_create(0, None, C.byref(ctx)) == 1
+for f in ("ovrfsr_set_config", "ovrfsr_get_config"):
+    assert getattr(L, f)(None, None) == 1 and getattr(L, f)(None, C.byref(cfg)) == 1
+assert L.ovrfsr_apply_batch(None, 1, 0, 1, None, 0, None, 0, None) == 1 and L.ovrfsr_apply_batch_shared(None, 1, None, 0, None, 0, None) == 1
+assert L.ovrfsr_last_gpu_time_ms(None, None) == 1 and L.ovrfsr_average_gpu_time_ms(None, None, None) == 1
+assert L.ovrfsr_pair_pending(None) == 0
+L.ovrfsr_easu_con.argtypes = [C.c_void_p] + [C.c_float] * 6; L.ovrfsr_easu_con.restype = None
+L.ovrfsr_easu_con(None, 1, 1, 1, 1, 2, 2)
+L.ovrfsr_rcas_con.argtypes = [C.c_void_p, C.c_float]; L.ovrfsr_rcas_con.restype = None
+L.ovrfsr_rcas_con(None, 0.2)
+L.ovrfsr_mask_constants.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_float, C.c_int, C.c_int]; L.ovrfsr_mask_constants.restype = None
+four = (C.c_uint32 * 4)(); proj = (C.c_float * 4)(0.5, 0.5, 0.5, 0.5)
+L.ovrfsr_mask_constants(None, four, 64, 64, proj, 0.5, 1, 0); L.ovrfsr_mask_constants(four, None, 64, 64, proj, 0.5, 1, 0); L.ovrfsr_mask_constants(four, four, 64, 64, None, 0.5, 1, 0)
+L.ovrfsr_nis_scaler_config.argtypes = [C.c_void_p, C.c_float] + [C.c_uint32] * 4
+L.ovrfsr_nis_sharpen_config.argtypes = [C.c_void_p, C.c_float] + [C.c_uint32] * 2
+assert L.ovrfsr_nis_scaler_config(None, 0.5, 8, 8, 10, 10) == 0 and L.ovrfsr_nis_sharpen_config(None, 0.5, 8, 8) == 0
+L.ovrfsr_config_from_json.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+assert L.ovrfsr_config_from_json(None, 5, C.byref(cfg)) == 1 and L.ovrfsr_config_from_json(b"{}", 2, None) == 1
+L.ovrfsr_save_ppm.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]; L.ovrfsr_save_dds.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+assert L.ovrfsr_save_ppm(None, b"/tmp/x.ppm", None) == 1 and L.ovrfsr_save_dds(None, b"/tmp/x.dds", None) == 1
+img = A.Image(); 
+assert L.ovrfsr_save_ppm(C.byref(img), None, None) == 1 and L.ovrfsr_save_dds(C.byref(img), None, None) == 1
+print("survived")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_create_without_gpu_reports_no_device():
     import torch
     if torch.cuda.is_available():
