@@ -61,6 +61,12 @@ static bool stream_capturing(hipStream_t s)
 static const char *const kCaptureRefusal = "this call has to build device resources (the first call for an input size, a larger batch, a new output image), "
                                            "which a capturing stream does not permit: make the same call once outside the capture";
 
+// Offsets and strides of a batch of two are taken modulo 2^64 (cfg.pair_submit: the second eye's image may lie BELOW the first one's): that is
+// integer arithmetic on the address, not pointer arithmetic -- `p += huge` is undefined beyond the object (UBSan on the R,L job of
+// tests/debug/thread_stress.c, round 6), the wrap of an unsigned sum is not.  The kernels add `i * stride` to a 64-bit base the same way.
+template <class T>
+static inline T *at_offset(T *p, size_t off) { return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + off); }
+
 // a*b+c with two roundings, identical to the kernels' mad_unfused (separate statements)
 static inline float mad2(float a, float b, float c)
 {
@@ -632,7 +638,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
             for (int p = 0; p < np && e == hipSuccess; ++p) {
                 NisArgs b = na;
                 const EyePass &ps = passes[p];
-                b.v.in += ps.inOff; b.v.out += ps.outOff; b.v.in_stride = ps.inStride; b.v.out_stride = ps.outStride;
+                b.v.in = at_offset(b.v.in, ps.inOff); b.v.out = at_offset(b.v.out, ps.outOff); b.v.in_stride = ps.inStride; b.v.out_stride = ps.outStride;
                 if (ps.split) { b.m.first_eye = (uint32_t)ps.eye; b.m.alternate = 0; }
                 if (nInside_[ps.eye]) {
                     b.tileList = tileListDev_ + listOffInside_[ps.eye];
@@ -661,7 +667,7 @@ int PostProcessor::ApplyUpscaling(uint32_t n, int firstEye, int alternate, const
         for (int p = 0; p < np && e == hipSuccess; ++p) {
             EasuArgs b = a;
             const EyePass &ps = passes[p];
-            b.v.in += ps.inOff; b.v.out += ps.outOff; b.v.in_stride = ps.inStride; b.v.out_stride = ps.outStride;
+            b.v.in = at_offset(b.v.in, ps.inOff); b.v.out = at_offset(b.v.out, ps.outOff); b.v.in_stride = ps.inStride; b.v.out_stride = ps.outStride;
             if (ps.split) { b.m.first_eye = (uint32_t)ps.eye; b.m.alternate = 0; }
             if (nInside_[ps.eye]) {
                 b.tileList = tileListDev_ + listOffInside_[ps.eye];
@@ -773,9 +779,9 @@ int PostProcessor::ApplySorted(uint32_t n, int firstEye, int alternate, const ov
         const EyePass &ms = midPasses[p];
         EasuArgs em = toMid, eo = toOut;
         RcasArgs rb = ra;
-        em.v.in += ps.inOff; em.v.in_stride = ps.inStride; em.v.out += ms.outOff; em.v.out_stride = ms.outStride;
-        eo.v.in += ps.inOff; eo.v.in_stride = ps.inStride; eo.v.out += ps.outOff; eo.v.out_stride = ps.outStride;
-        rb.v.in += ms.inOff; rb.v.in_stride = ms.inStride; rb.v.out += ps.outOff; rb.v.out_stride = ps.outStride;
+        em.v.in = at_offset(em.v.in, ps.inOff); em.v.in_stride = ps.inStride; em.v.out = at_offset(em.v.out, ms.outOff); em.v.out_stride = ms.outStride;
+        eo.v.in = at_offset(eo.v.in, ps.inOff); eo.v.in_stride = ps.inStride; eo.v.out = at_offset(eo.v.out, ps.outOff); eo.v.out_stride = ps.outStride;
+        rb.v.in = at_offset(rb.v.in, ms.inOff); rb.v.in_stride = ms.inStride; rb.v.out = at_offset(rb.v.out, ps.outOff); rb.v.out_stride = ps.outStride;
         if (ps.split) {
             em.m.first_eye = eo.m.first_eye = rb.m.first_eye = (uint32_t)ps.eye;
             em.m.alternate = eo.m.alternate = rb.m.alternate = 0;
@@ -837,7 +843,7 @@ int PostProcessor::ApplyFused(uint32_t n, int firstEye, int alternate, const ovr
             const EyePass &ps = passes[p];
             FusedArgs fb = a;
             EasuArgs eb = ea;
-            fb.v.in += ps.inOff; fb.v.out += ps.outOff; fb.v.in_stride = ps.inStride; fb.v.out_stride = ps.outStride;
+            fb.v.in = at_offset(fb.v.in, ps.inOff); fb.v.out = at_offset(fb.v.out, ps.outOff); fb.v.in_stride = ps.inStride; fb.v.out_stride = ps.outStride;
             eb.v = fb.v;
             if (ps.split) { fb.m.first_eye = eb.m.first_eye = (uint32_t)ps.eye; fb.m.alternate = eb.m.alternate = 0; }
             if (nInside_[ps.eye]) {

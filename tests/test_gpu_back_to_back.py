@@ -11,6 +11,8 @@ loop), every B result the first B result, bit for bit.  Also through `ovrfsr_app
 Mutation check (rounds 4-5, GPU): a library built with -DOVRFSR_MUTATE_NO_JOIN (the aux stream's join edge dropped) fails these tests
 (since round 5 only half-float sources fork; the RGBA8 cases run in order on the caller's stream and keep their place as
 ordering tests of the shared intermediate)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -456,3 +458,61 @@ def test_pair_submit_falls_back_to_single_launches():
         assert int(outs[0].max()) == 0
     finally:
         pp.close()
+
+
+def test_hours_of_rebuilds_do_not_leak():
+    """A VR session lasts hours and every hotkey, every resolution change and every recovered failure rebuilds the ctx's device resources (tile
+    lists, tap tables, coefficient banks, the intermediate, events, the auxiliary stream).  2 400 rebuilds through every path that triggers one
+    -- set_config, reset, an input-size change, pair_submit's retired image, ctx create / destroy -- and then: the device has as much free memory
+    as before (hipMemGetInfo) and the process has not grown (RSS), within the allocators' granularity."""
+    import copy
+    import gc
+    import psutil
+    import torch
+    import openvr_fsr_amd as A
+    ow, oh = 427, 360
+    srcs = {s: _batch(np.uint8, 21, 2, *s) for s in ((320, 270), (256, 200), (300, 240))}
+    srcs16 = _batch(np.float16, 22, 2, 320, 270)
+    out = torch.zeros((2, oh, ow, 4), dtype=torch.uint8, device="cuda")
+    out16 = torch.zeros((2, oh, ow, 4), dtype=torch.float16, device="cuda")
+
+    def cycle(n):
+        pp = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, radius=0.5, sharpness=0.9, debug_mode=1)
+        ph = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, radius=0.5, sharpness=0.9)                    # half: fused + forked outside kernel
+        pq = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, radius=0.6, sharpness=0.9, pair_submit=1)     # ctx-owned outputs, retired images
+        cfgs = []
+        for r, nis in ((0.5, 0), (0.7, 0), (2.0, 0), (0.45, 1)):
+            c = copy.copy(pp.cfg); c.radius = r; c.use_nis = nis; cfgs.append(c)
+        sizes = list(srcs)
+        for i in range(n):
+            pp.set_config(cfgs[i % 4])                       # hotkey: rebuild on the next apply
+            pp.apply_batch(srcs[sizes[i % 3]], out)          # ... and an input-size change two times out of three
+            if i % 5 == 0:
+                pp.reset()
+            ph.apply_batch(srcs16, out16)
+            if i % 7 == 0:
+                ph.reset()
+            t = srcs[sizes[(i // 2) % 3]]
+            pq.apply(0, t[0]); pq.apply(1, t[1])             # the size changes every other frame: the recorded eye's image is retired
+            if i % 50 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        for p in (pp, ph, pq):
+            p.close()
+        for _ in range(n // 8):                              # ctx life cycle
+            p = A.PostProcessor(fsr_enabled=1, out_width=ow, out_height=oh, radius=0.5)
+            p.apply_batch(srcs[(320, 270)], out)
+            p.close()
+        torch.cuda.synchronize()
+
+    cycle(40)                                                # warm-up: code objects, torch's caches, the runtime's pools
+    gc.collect()
+    free0, _ = torch.cuda.mem_get_info()
+    rss0 = psutil.Process().memory_info().rss
+    cycle(int(os.environ.get("OVRFSR_LEAK_CYCLES", "600")))   # 600 x (1 + ~0.67 + ...) rebuilds on pp, ph resets, 300 retired images, 75 ctxs
+    gc.collect()
+    free1, _ = torch.cuda.mem_get_info()
+    rss1 = psutil.Process().memory_info().rss
+    print("leak test: device free %+.2f MiB, host RSS %+.2f MiB over the cycle" % ((free1 - free0) / 2 ** 20, (rss1 - rss0) / 2 ** 20))
+    assert free0 - free1 <= 16 << 20, "device memory shrank by %.1f MiB over the cycle" % ((free0 - free1) / 2 ** 20)
+    assert rss1 - rss0 <= 48 << 20, "host RSS grew by %.1f MiB over the cycle" % ((rss1 - rss0) / 2 ** 20)

@@ -17,9 +17,10 @@ mkdir -p "$ROOT/ab"
 make -C "$ROOT/openvr_fsr_amd/csrc" -j8 EXTRA="$SAN --offload-compress" LDEXTRA="-fsanitize=address,undefined" BUILD=build_asan OUT=../../ab/asan.so 2>&1 | grep -v "option-ignored\|^/opt/rocm\|^make" || true
 test -f "$ROOT/ab/asan.so"
 ROCM=${ROCM_PATH:-/opt/rocm}
-for ex in headless bench_node; do
+for ex in headless bench_node thread_stress; do
+    SRC="$ROOT/examples/$ex.c"; [ -f "$SRC" ] || SRC="$ROOT/tests/debug/$ex.c"   # (thread_stress.c lives with the tests)
     # (-shared-libasan: the drivers use the runtime as a shared object -- 30 KB each instead of 3.2 MB of statically linked runtime to push to the GPU box)
-    $CLANG -std=c11 -O1 -g $SAN -shared-libasan -pthread -D_POSIX_C_SOURCE=200809L -D__HIP_PLATFORM_AMD__ "$ROOT/examples/$ex.c" -I"$ROOT/include" -I"$ROCM/include" \
+    $CLANG -std=c11 -O1 -g $SAN -shared-libasan -pthread -D_POSIX_C_SOURCE=200809L -D__HIP_PLATFORM_AMD__ "$SRC" -I"$ROOT/include" -I"$ROCM/include" \
         "$ROOT/ab/asan.so" -L"$ROCM/lib" -lamdhip64 -lm -Wl,-rpath,"\$ORIGIN" -Wl,-rpath,"$ROCM/lib" -Wl,-rpath,"$(dirname "$RT")" -o "$ROOT/ab/${ex}_asan"
 done
 # The same host translation units under GCC's AddressSanitizer + UBSan, linked with the PRODUCT's kernel objects -> ab/asan_gcc.so: the one
@@ -37,4 +38,4 @@ done
 ${HIPCC:-$ROCM/bin/hipcc} --offload-arch=gfx950 -shared -fPIC -o "$ROOT/ab/asan_gcc.so" "$ROOT"/openvr_fsr_amd/csrc/build_asan_gcc/*.o \
     "$ROOT/openvr_fsr_amd/csrc/build_z/fsr_kernels.o" "$ROOT/openvr_fsr_amd/csrc/build_z/nis_kernels.o"
 python3 "$ROOT/tools/variant_fresh.py" --stamp asan "$SAN"
-echo "built ab/asan.so ab/asan_gcc.so ab/headless_asan ab/bench_node_asan"
+echo "built ab/asan.so ab/asan_gcc.so ab/headless_asan ab/bench_node_asan ab/thread_stress_asan"
