@@ -47,9 +47,17 @@ NK = len(KINDS)
 PAD_ALLOWED = {"K_EASU_LUM", "K_BIL_X", "K_BIL_Y"}
 
 
+def checked_build():
+    return hasattr(A.library(), "ovrfsr_debug_bounds")
+
+
 def counters(reset=False):
     lib = A.library()
-    fn = lib.ovrfsr_debug_bounds            # AttributeError: not a checked build
+    if not checked_build():
+        # not a checked build: the campaign still DRIVES every configuration -- what the host-side sanitizer build wants (OVRFSR_LIB=ab/asan_gcc.so:
+        # tile lists, tap tables and argument blocks of thousands of shapes built under AddressSanitizer); every count reads 0
+        return {"oob": dict.fromkeys(KINDS, 0), "pad": dict.fromkeys(KINDS, 0), "checked": dict.fromkeys(KINDS, 0), "first": None}
+    fn = lib.ovrfsr_debug_bounds
     fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int, ctypes.c_int]
     n = lib.ovrfsr_debug_bounds_slots()
     assert n == 3 * NK + 5, (n, NK)
@@ -86,6 +94,9 @@ def collect(tag):
 
 def selftest():
     lib = A.library()
+    if not checked_build():
+        print("selftest: skipped (not a checked build: configurations are driven, nothing is counted)", flush=True)
+        return True
     counters(reset=True)
     assert lib.ovrfsr_debug_bounds_selftest() == 0
     c = counters(reset=True)
