@@ -62,6 +62,17 @@ static inline const float *texel_clamp(const image_t *im, int x, int y)
 }
 static inline float getY(const float *c) { return 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }
 
+/* The reference fills its luma tiles with SampleLevel at TEXEL CENTRES (NIS_Scaler.h:653, 902; NIS_TEXTURE_GATHER is off in this build): the
+ * snapped coordinate has fraction 0, so the four taps carry the weights 1, 0, 0, 0 -- the texel itself for every finite image, but a NaN / Inf
+ * neighbour to the right or below still enters as 0 x NaN.  Restated as written (round 6: the pin campaign's non-finite family). */
+static inline float luma_centre(const image_t *im, int x, int y)
+{
+    const float *c00 = texel_clamp(im, x, y), *c10 = texel_clamp(im, x + 1, y), *c01 = texel_clamp(im, x, y + 1), *c11 = texel_clamp(im, x + 1, y + 1);
+    float s[3];
+    for (int ch = 0; ch < 3; ++ch) s[ch] = ((c00[ch] * 1.0f + c10[ch] * 0.0f) + c01[ch] * 0.0f) + c11[ch] * 0.0f;
+    return getY(s);
+}
+
 static inline void fixed8(float t, int *i0, float *frac)
 {
     float s = floorf(t * 256.0f + 0.5f);
@@ -297,7 +308,7 @@ OVO_API int ovo_nis_upscale(const float *in, int inW, int inH, float *out, int o
         for (int x = 0; x < PW; ++x) {
             float q[3][3];
             for (int r = 0; r < 3; ++r)
-                for (int c = 0; c < 3; ++c) q[r][c] = getY(texel_clamp(&im, x - PAD - 1 + c, y - PAD - 1 + r));
+                for (int c = 0; c < 3; ++c) q[r][c] = luma_centre(&im, x - PAD - 1 + c, y - PAD - 1 + r);
             edge_map(E + 4 * ((size_t)y * PW + x), q, &cb);
             Y[(size_t)y * PW + x] = q[1][1] * 255.0f;
         }
@@ -404,7 +415,7 @@ OVO_API int ovo_nis_sharpen(const float *in, int W, int H, float *out, const voi
                      * 5x5 support of pixel = cells pos..pos+4 = texels dst-2..dst+2 */
                     float p[5][5];
                     for (int i = 0; i < 5; ++i)
-                        for (int j = 0; j < 5; ++j) p[i][j] = getY(texel_clamp(&im, dstX - 2 + j, dstY - 2 + i));
+                        for (int j = 0; j < 5; ++j) p[i][j] = luma_centre(&im, dstX - 2 + j, dstY - 2 + i);
                     const float scaleY = 1.0f - sat((p[2][2] - cb.kSharpStartY) * cb.kSharpScaleY);
                     const float strength = scaleY * cb.kSharpStrengthScale + cb.kSharpStrengthMin;
                     const float limit = (scaleY * cb.kSharpLimitScale + cb.kSharpLimitMin) * p[2][2];

@@ -5,8 +5,10 @@ Everything in this repository is measured against oracle/ (the C restatement); t
 own HLSL bodies compiled through oracle/hlsl_shim.hpp -- by tests/test_oracle*.py on a handful of seeds.  This campaign runs the same comparison,
 bit for bit, for as long as it is given: random sizes (8..260) and scales (0.5..1), mask radii and centres, both eyes, debug tint on / off, sharpness
 0..1; content families: the three synthetic generators, crops of the natural fixtures, HDR floats (unit content x 6 / x 40), and WILD floats
-(negative values, denormals, zeros and 1e30s, no NaN / Inf); a further family holds NaN / Inf texels and is reported separately (HLSL leaves min / max
-of a NaN to the implementation: the shim and the restatement agree on IEEE fmin / fmax semantics, which is what is compared).
+(negative values, denormals, zeros and 1e30s, no NaN / Inf); a seventh family holds NaN / Inf texels (HLSL leaves min / max of a NaN to the
+implementation: the shim and the restatement agree on IEEE fmin / fmax semantics, which is what is compared; two NaNs count as equal).  That family
+found the one place where the restatement took a shortcut that only non-finite texels can see -- NIS luma tiles loaded as texels instead of through
+the reference's SampleLevel at texel centres (weights 1, 0, 0, 0: 0 x NaN) -- restated since; all seven families agree.
 Stages: EASU, RCAS behind the UNORM8-quantised EASU result and behind the float one, NVScaler, NVSharpen."""
 import os
 import sys

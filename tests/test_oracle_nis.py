@@ -74,3 +74,36 @@ def test_nis_invariants():
     img = O.unorm8_to_float(synth.extremes_u8(w, h, 2))
     out = O.nis_upscale(img, ow, oh, blk, cs, cu)
     assert out.min() >= 0.0 and out.max() <= 1.0 and (out[..., 3] == 1.0).all()
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference on this box)")
+@pytest.mark.parametrize("seed", [6, 13, 20])
+def test_oracle_matches_reference_on_non_finite_texels(seed):
+    """NaN / +-Inf / 1e30 texels (outside the parity contract of the LIBRARY, header "TEXEL VALUES") still have one answer in the reference's
+    arithmetic, and the restatement gives it: the round-6 pin campaign (tests/debug/oracle_pin_campaign.py) found the single shortcut only such
+    texels can see -- NIS luma tiles loaded as texels instead of through SampleLevel at texel centres, where a NaN neighbour enters as 0 x NaN --
+    and this keeps it closed, for EASU / RCAS / NVScaler / NVSharpen.  Two NaNs compare equal whatever their payload."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "debug"))
+    import oracle_pin_campaign as P
+    rng = np.random.default_rng(seed)
+    iw, ih = int(rng.integers(20, 90)), int(rng.integers(20, 90))
+    ow, oh = int(iw / 0.75), int(ih / 0.75)
+    img = P.content(6, iw, ih, seed, rng)
+    assert np.isnan(img).any() and np.isinf(img).any()
+    cs, cu = O.ref_nis_coefs()
+    centre, rad = O.mask_constants(ow, oh, 2.0)
+    con = O.easu_con(iw, ih, ow, oh)
+    a = O.easu(img, ow, oh, con, centre, rad)
+    assert P.same_bits(a, O.ref_easu(img, ow, oh, con, centre, rad))
+    rcon = O.rcas_con(0.6, 0)
+    assert P.same_bits(O.rcas(a, rcon, centre, rad), O.ref_rcas(a, rcon, centre, rad))
+    ok, cfg = O.ref_nis_scaler_config(0.5, iw, ih, ow, oh)
+    assert ok
+    blk = O.nis_block(cfg, centre, rad, 0)
+    assert P.same_bits(O.nis_upscale(img, ow, oh, blk, cs, cu), O.ref_nis_upscale(img, ow, oh, blk, cs, cu))
+    ok, cfg = O.ref_nis_scaler_config(0.5, iw, ih, iw, ih)
+    c2, r2 = O.mask_constants(iw, ih, 2.0)
+    blk = O.nis_block(cfg, c2, r2, 0)
+    assert P.same_bits(O.nis_sharpen(img, blk), O.ref_nis_sharpen(img, blk, cs, cu))
